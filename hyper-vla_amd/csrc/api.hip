@@ -1,0 +1,500 @@
+// api.hip — the C ABI of libhvla (include/hvla.h): context, weight packing, launch sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/hvla.h"
+#include "common.h"
+#include "kernels.h"
+#include "layout.h"
+
+using namespace hvla;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    return n ? hipMalloc(&p, n) : hipSuccess;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline uint16_t f2bf(float f) {          // round-to-nearest-even, NaN preserved
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline uint16_t f2h(float f) {
+  _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+
+}  // namespace
+
+struct hvla_weights {
+  int B = 0;
+  DevBuf wh, wl, vf, ctx, ring, count;
+};
+
+struct hvla_ctx {
+  hvla_config cfg{};
+  Geom g{};
+  int device = 0;
+  std::string err;
+  bool loaded = false;
+  PackedLayout lay;
+  int Kp = 0;
+  // device weights
+  DevBuf hn_f32;                 // context-encoder parameters, natural flax layout
+  CtxParams ctxp{};
+  DevBuf wcat_hi, wcat_lo, bcat, perm;
+  DevBuf enc16, encf32;          // encoder matrices (16-bit) and vectors (f32)
+  EncWeights encw{};
+  // workspaces (sized for cfg.max_batch)
+  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, tokens, flags;
+};
+
+#define FAIL(ctx, code, ...)                       \
+  do {                                             \
+    char _b[512];                                  \
+    snprintf(_b, sizeof _b, __VA_ARGS__);          \
+    (ctx)->err = _b;                               \
+    return (code);                                 \
+  } while (0)
+#define HIPCHK(ctx, call)                                                               \
+  do {                                                                                  \
+    hipError_t _e = (call);                                                             \
+    if (_e != hipSuccess) FAIL(ctx, HVLA_E_HIP, "%s: %s", #call, hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" {
+
+const char* hvla_last_error(const hvla_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
+  if (!c || !out) return HVLA_E_SHAPE;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return HVLA_E_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HVLA_E_DEVICE;
+  if (!strstr(prop.gcnArchName, "gfx950")) return HVLA_E_DEVICE;   // CDNA4 only: no fallback path
+  std::unique_ptr<hvla_ctx> ctx(new hvla_ctx);
+  ctx->cfg = *c;
+  ctx->device = device;
+  Geom& g = ctx->g;
+  g = Geom{c->image_size, c->patch, c->enc_dim, c->enc_layers, c->enc_heads, c->enc_mlp,
+           c->dim, c->layers, c->heads, c->mlp, c->horizon, c->action_dim, c->tanh_scale, c->max_action,
+           c->ctx_dim, c->ctx_layers, c->ctx_heads, c->ctx_mlp, c->lang_tokens, c->lang_dim, c->scale_context};
+  // what the hand-written kernels are specialised for (anything else is refused, never emulated)
+  const int P = g.P();
+  const bool ok = c->dim == 64 && c->heads == 4 && c->mlp % 32 == 0 && c->mlp >= 32 && c->enc_dim % 128 == 0 &&
+                  c->enc_dim <= 1024 && c->enc_mlp % 128 == 0 && c->enc_dim / c->enc_heads == 64 &&
+                  (P == 256 || P == 64 || P == 32) && c->image_size % c->patch == 0 &&
+                  (c->ctx_dim == 128 || c->ctx_dim == 64 || c->ctx_dim == 32) && c->ctx_dim % c->ctx_heads == 0 &&
+                  c->ctx_mlp % 4 == 0 && c->lang_tokens + 2 <= 40 && c->lang_tokens >= 2 && c->lang_dim % 4 == 0 &&
+                  c->ctx_layers <= CTX_MAX_LAYERS && c->enc_layers <= ENC_MAX_LAYERS && c->layers >= 1 &&
+                  c->horizon * (c->action_dim - 1) + c->horizon <= 32 && c->max_batch >= 1 &&
+                  (c->enc_dtype == HVLA_ENC_F16 || c->enc_dtype == HVLA_ENC_BF16);
+  if (!ok) return c->enc_dtype != HVLA_ENC_F16 && c->enc_dtype != HVLA_ENC_BF16 ? HVLA_E_DTYPE : HVLA_E_SHAPE;
+  if (hipSetDevice(device) != hipSuccess) return HVLA_E_DEVICE;
+  ctx->lay = build_layout(g);
+  ctx->Kp = (g.patch * g.patch * 3 + 63) / 64 * 64;
+  {  // the packed order must be a bijection onto the reference parameter vector
+    std::vector<uint8_t> seen(ctx->lay.pl.G, 0);
+    for (int32_t r : ctx->lay.perm)
+      if (r >= 0) {
+        if (r >= ctx->lay.pl.G || seen[r]) return HVLA_E_STATE;
+        seen[r] = 1;
+      }
+    for (uint8_t s : seen)
+      if (!s) return HVLA_E_STATE;
+  }
+  const size_t Bm = c->max_batch, S = g.S(), E = g.E, F = g.enc_mlp;
+  size_t gbytes = Bm * S * F * 2;
+  if (gbytes < Bm * P * ctx->Kp * 2) gbytes = Bm * P * ctx->Kp * 2;
+  hipError_t e = hipSuccess;
+  auto A = [&](DevBuf& b, size_t n) { if (e == hipSuccess) e = b.alloc(n); };
+  A(ctx->ctx_hi, Bm * g.C * 2); A(ctx->ctx_lo, Bm * g.C * 2); A(ctx->ctx_f32, Bm * g.C * 4);
+  A(ctx->ws_x, Bm * S * E * 4); A(ctx->ws_h, Bm * S * E * 2); A(ctx->ws_qkv, Bm * S * 3 * E * 2);
+  A(ctx->ws_g, gbytes); A(ctx->tokens, Bm * P * E * 4); A(ctx->flags, 64 * sizeof(int));
+  if (e != hipSuccess) return HVLA_E_ARENA_FULL;
+  *out = ctx.release();
+  return HVLA_OK;
+}
+
+void hvla_destroy(hvla_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  delete ctx;
+}
+
+int64_t hvla_num_generated(const hvla_ctx* ctx) { return ctx ? ctx->lay.pl.G : 0; }
+
+int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
+  if (!ctx) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const Geom& g = ctx->g;
+  std::map<std::string, const hvla_tensor_desc*> m;
+  for (int i = 0; i < n; ++i) {
+    if (!t[i].name || !t[i].data) FAIL(ctx, HVLA_E_WEIGHTS, "tensor %d has null name/data", i);
+    m[t[i].name] = &t[i];
+  }
+  const char* missing = nullptr;
+  std::string missing_s;
+  auto get = [&](const std::string& name, int64_t numel) -> const float* {
+    auto it = m.find(name);
+    if (it == m.end() || it->second->numel != numel) {
+      if (!missing) {
+        missing_s = name + (it == m.end() ? " (absent)" : " (wrong size)");
+        missing = missing_s.c_str();
+      }
+      return nullptr;
+    }
+    return it->second->data;
+  };
+  const int C = g.C, Hc = g.ctx_heads, F = g.ctx_mlp, T = g.T, E = g.E;
+  // ------------------------------------------------------------ context encoder (f32, natural layout)
+  std::vector<float> hn;
+  std::vector<std::pair<const float**, size_t>> fix;     // pointer slot -> offset
+  auto push = [&](const float** slot, const std::string& name, int64_t numel) {
+    const float* src = get(name, numel);
+    const size_t off = hn.size();
+    hn.resize(off + ((numel + 3) / 4) * 4, 0.f);
+    if (src) memcpy(hn.data() + off, src, numel * 4);
+    fix.push_back({slot, off});
+  };
+  CtxParams& cp = ctx->ctxp;
+  cp = CtxParams{};
+  cp.T = T; cp.C = C; cp.F = F; cp.heads = Hc; cp.layers = g.ctx_layers; cp.lang_dim = g.lang_dim; cp.E = E;
+  cp.scale_context = g.scale_context;
+  push(&cp.w_tok, "task_token_projection/kernel", (int64_t)g.lang_dim * C);
+  push(&cp.b_tok, "task_token_projection/bias", C);
+  push(&cp.w_img, "initial_image_projection/kernel", (int64_t)E * C);
+  push(&cp.b_img, "initial_image_projection/bias", C);
+  push(&cp.pos_tok, "task_pos_embedding", (int64_t)T * C);
+  push(&cp.pos_img, "initial_image_pos_embedding", C);
+  push(&cp.pos_layer, "layer_pos_embedding", C);
+  push(&cp.norm_s, "Transformer_0/encoder_norm/scale", C);
+  push(&cp.norm_b, "Transformer_0/encoder_norm/bias", C);
+  for (int l = 0; l < g.ctx_layers; ++l) {
+    const std::string b = "Transformer_0/encoderblock_" + std::to_string(l) + "/";
+    const std::string a = b + "MultiHeadDotProductAttention_0/";
+    CtxLayer& L = cp.layer[l];
+    push(&L.ln0_s, b + "LayerNorm_0/scale", C); push(&L.ln0_b, b + "LayerNorm_0/bias", C);
+    push(&L.wq, a + "query/kernel", (int64_t)C * C); push(&L.bq, a + "query/bias", C);
+    push(&L.wk, a + "key/kernel", (int64_t)C * C); push(&L.bk, a + "key/bias", C);
+    push(&L.wv, a + "value/kernel", (int64_t)C * C); push(&L.bv, a + "value/bias", C);
+    push(&L.wo, a + "out/kernel", (int64_t)C * C); push(&L.bo, a + "out/bias", C);
+    push(&L.ln1_s, b + "LayerNorm_1/scale", C); push(&L.ln1_b, b + "LayerNorm_1/bias", C);
+    push(&L.w1, b + "MlpBlock_0/Dense_0/kernel", (int64_t)C * F); push(&L.b1, b + "MlpBlock_0/Dense_0/bias", F);
+    push(&L.w2, b + "MlpBlock_0/Dense_1/kernel", (int64_t)F * C); push(&L.b2, b + "MlpBlock_0/Dense_1/bias", C);
+  }
+  // ------------------------------------------------------------ W_cat / b_cat in packed order
+  const PolicyLayout& pl = ctx->lay.pl;
+  const int Gtot = pl.Gm + pl.Gv, ntiles = Gtot / 32, KS = C / 16;
+  auto leaves = generated_leaves(g);
+  std::vector<const float*> lk(leaves.size()), lb(leaves.size());
+  std::vector<int32_t> leaf_of(pl.G);
+  for (size_t i = 0; i < leaves.size(); ++i) {
+    lk[i] = get("output_head_" + leaves[i].flat + "/kernel", (int64_t)C * leaves[i].size);
+    lb[i] = get("output_head_" + leaves[i].flat + "/bias", leaves[i].size);
+    for (int64_t j = 0; j < leaves[i].size; ++j) leaf_of[leaves[i].offset + j] = (int32_t)i;
+  }
+  // ------------------------------------------------------------ DINOv2 (shared leaves, flat vectors)
+  const std::string ep = "encoder_image_encoder_";
+  const int Fe = g.enc_mlp, p = g.patch, S = g.S(), Kp = ctx->Kp, Kreal = p * p * 3;
+  const float* e_cls = get(ep + "embeddings_cls_token", E);
+  (void)get(ep + "embeddings_mask_token", E);
+  const float* e_pk = get(ep + "embeddings_patch_embeddings_projection_kernel", (int64_t)Kreal * E);
+  const float* e_pb = get(ep + "embeddings_patch_embeddings_projection_bias", E);
+  const float* e_pos = get(ep + "embeddings_position_embeddings", (int64_t)S * E);
+  const float* e_lns = get(ep + "layernorm_scale", E);
+  const float* e_lnb = get(ep + "layernorm_bias", E);
+  struct LSrc { const float *q, *qb, *k, *kb, *v, *vb, *o, *ob, *l1, *l2, *f1, *f1b, *f2, *f2b, *n1s, *n1b, *n2s, *n2b; };
+  std::vector<LSrc> ls(g.enc_layers);
+  for (int i = 0; i < g.enc_layers; ++i) {
+    const std::string L = ep + "encoder_layer_" + std::to_string(i) + "_";
+    LSrc& s = ls[i];
+    s.q = get(L + "attention_attention_query_kernel", (int64_t)E * E); s.qb = get(L + "attention_attention_query_bias", E);
+    s.k = get(L + "attention_attention_key_kernel", (int64_t)E * E); s.kb = get(L + "attention_attention_key_bias", E);
+    s.v = get(L + "attention_attention_value_kernel", (int64_t)E * E); s.vb = get(L + "attention_attention_value_bias", E);
+    s.o = get(L + "attention_output_dense_kernel", (int64_t)E * E); s.ob = get(L + "attention_output_dense_bias", E);
+    s.l1 = get(L + "layer_scale1_lambda1", E); s.l2 = get(L + "layer_scale2_lambda1", E);
+    s.f1 = get(L + "mlp_fc1_kernel", (int64_t)E * Fe); s.f1b = get(L + "mlp_fc1_bias", Fe);
+    s.f2 = get(L + "mlp_fc2_kernel", (int64_t)Fe * E); s.f2b = get(L + "mlp_fc2_bias", E);
+    s.n1s = get(L + "norm1_scale", E); s.n1b = get(L + "norm1_bias", E);
+    s.n2s = get(L + "norm2_scale", E); s.n2b = get(L + "norm2_bias", E);
+  }
+  if (missing) FAIL(ctx, HVLA_E_WEIGHTS, "checkpoint tensor %s", missing);
+
+  // ---- upload the context encoder
+  HIPCHK(ctx, ctx->hn_f32.alloc(hn.size() * 4));
+  HIPCHK(ctx, hipMemcpy(ctx->hn_f32.p, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
+  for (auto& f : fix) *f.first = ctx->hn_f32.as<float>() + f.second;
+
+  // ---- pack W_cat^T fragments (layout.h): tile pt, k-step ks, lane (rho = l & 31, hk = l >> 5), j
+  {
+    std::vector<uint16_t> hi((size_t)ntiles * KS * 512), lo(hi.size());
+    std::vector<float> bc(Gtot, 0.f);
+    const int32_t* perm = ctx->lay.perm.data();
+    for (int pos = 0; pos < Gtot; ++pos)
+      if (perm[pos] >= 0) {
+        const int ref = perm[pos], li = leaf_of[ref];
+        bc[pos] = lb[li][ref - leaves[li].offset];
+      }
+    for (int pt = 0; pt < ntiles; ++pt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int rho = lane & 31, hk = lane >> 5;
+        const int tau = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+        const int ref = perm[pt * 32 + tau];
+        const float* col = nullptr;
+        int64_t n_leaf = 0;
+        if (ref >= 0) {
+          const int li = leaf_of[ref];
+          col = lk[li] + (ref - leaves[li].offset);
+          n_leaf = leaves[li].size;
+        }
+        for (int ks = 0; ks < KS; ++ks)
+          for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * hk + j;
+            const float w = col ? col[(int64_t)k * n_leaf] : 0.f;
+            const uint16_t h = f2bf(w);
+            const size_t o = ((size_t)(pt * KS + ks) * 64 + lane) * 8 + j;
+            hi[o] = h;
+            lo[o] = f2bf(w - bf2f(h));
+          }
+      }
+    HIPCHK(ctx, ctx->wcat_hi.alloc(hi.size() * 2));
+    HIPCHK(ctx, ctx->wcat_lo.alloc(lo.size() * 2));
+    HIPCHK(ctx, ctx->bcat.alloc(bc.size() * 4));
+    HIPCHK(ctx, ctx->perm.alloc(ctx->lay.perm.size() * 4));
+    HIPCHK(ctx, hipMemcpy(ctx->wcat_hi.p, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->wcat_lo.p, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->bcat.p, bc.data(), bc.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->perm.p, ctx->lay.perm.data(), ctx->lay.perm.size() * 4, hipMemcpyHostToDevice));
+  }
+
+  // ---- pack the image encoder: 16-bit [N][K] matrices, f32 vectors
+  {
+    const bool bf = ctx->cfg.enc_dtype == HVLA_ENC_BF16;
+    auto cv = [&](float f) { return bf ? f2bf(f) : f2h(f); };
+    const size_t per_layer16 = (size_t)3 * E * E + (size_t)E * E + (size_t)2 * E * Fe;
+    std::vector<uint16_t> w16((size_t)E * Kp + per_layer16 * g.enc_layers);
+    const size_t per_layerf = (size_t)3 * E + E + Fe + E + 6 * (size_t)E;
+    std::vector<float> wf((size_t)E + (size_t)S * E + 2 * (size_t)E + per_layerf * g.enc_layers);
+    size_t o16 = 0, of = 0;
+    std::vector<size_t> off16, offf;
+    auto mark16 = [&](size_t n) { off16.push_back(o16); o16 += n; };
+    auto markf = [&](size_t n) { offf.push_back(of); of += n; };
+    // patch embedding: fold (x/255 - mean)/std; weights stored x256 so small values keep 16-bit precision
+    const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
+    mark16((size_t)E * Kp);
+    markf(E);
+    for (int nn = 0; nn < E; ++nn) {
+      double bacc = e_pb[nn];
+      for (int k = 0; k < Kp; ++k) {
+        float w = 0.f;
+        if (k < Kreal) {
+          const int c = k % 3;
+          const double wk = e_pk[(size_t)k * E + nn];
+          w = (float)(wk * 256.0 / (255.0 * sd[c]));
+          bacc -= wk * mean[c] / sd[c];
+        }
+        w16[off16.back() + (size_t)nn * Kp + k] = cv(w);
+      }
+      wf[offf.back() + nn] = (float)bacc;
+    }
+    markf((size_t)S * E);
+    for (size_t i = 0; i < (size_t)S * E; ++i) wf[offf.back() + i] = e_pos[i] + (i < (size_t)E ? e_cls[i] : 0.f);
+    markf(E); memcpy(&wf[offf.back()], e_lns, E * 4);
+    markf(E); memcpy(&wf[offf.back()], e_lnb, E * 4);
+    auto tr = [&](const float* src, int K, int N, size_t dst) {   // flax [K][N] -> [N][K] 16-bit
+      for (int nn = 0; nn < N; ++nn)
+        for (int k = 0; k < K; ++k) w16[dst + (size_t)nn * K + k] = cv(src[(size_t)k * N + nn]);
+    };
+    for (int i = 0; i < g.enc_layers; ++i) {
+      const LSrc& s = ls[i];
+      mark16((size_t)3 * E * E);
+      tr(s.q, E, E, off16.back()); tr(s.k, E, E, off16.back() + (size_t)E * E); tr(s.v, E, E, off16.back() + (size_t)2 * E * E);
+      mark16((size_t)E * E); tr(s.o, E, E, off16.back());
+      mark16((size_t)E * Fe); tr(s.f1, E, Fe, off16.back());
+      mark16((size_t)Fe * E); tr(s.f2, Fe, E, off16.back());
+      markf(3 * E);
+      memcpy(&wf[offf.back()], s.qb, E * 4); memcpy(&wf[offf.back() + E], s.kb, E * 4); memcpy(&wf[offf.back() + 2 * E], s.vb, E * 4);
+      markf(E); memcpy(&wf[offf.back()], s.ob, E * 4);
+      markf(Fe); memcpy(&wf[offf.back()], s.f1b, Fe * 4);
+      markf(E); memcpy(&wf[offf.back()], s.f2b, E * 4);
+      const float* six[6] = {s.n1s, s.n1b, s.n2s, s.n2b, s.l1, s.l2};
+      for (int q = 0; q < 6; ++q) { markf(E); memcpy(&wf[offf.back()], six[q], E * 4); }
+    }
+    HIPCHK(ctx, ctx->enc16.alloc(w16.size() * 2));
+    HIPCHK(ctx, ctx->encf32.alloc(wf.size() * 4));
+    HIPCHK(ctx, hipMemcpy(ctx->enc16.p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->encf32.p, wf.data(), wf.size() * 4, hipMemcpyHostToDevice));
+    const uint16_t* d16 = ctx->enc16.as<uint16_t>();
+    const float* df = ctx->encf32.as<float>();
+    EncWeights& w = ctx->encw;
+    size_t i16 = 0, iff = 0;
+    w.w_patch = d16 + off16[i16++];
+    w.b_patch = df + offf[iff++];
+    w.pos = df + offf[iff++];
+    w.lnf_s = df + offf[iff++];
+    w.lnf_b = df + offf[iff++];
+    for (int i = 0; i < g.enc_layers; ++i) {
+      EncLayerW& L = w.layer[i];
+      L.wqkv = d16 + off16[i16++]; L.wo = d16 + off16[i16++]; L.w1 = d16 + off16[i16++]; L.w2 = d16 + off16[i16++];
+      L.bqkv = df + offf[iff++]; L.bo = df + offf[iff++]; L.b1 = df + offf[iff++]; L.b2 = df + offf[iff++];
+      L.ln1_s = df + offf[iff++]; L.ln1_b = df + offf[iff++]; L.ln2_s = df + offf[iff++]; L.ln2_b = df + offf[iff++];
+      L.ls1 = df + offf[iff++]; L.ls2 = df + offf[iff++];
+    }
+  }
+  HIPCHK(ctx, hipDeviceSynchronize());
+  ctx->loaded = true;
+  return HVLA_OK;
+}
+
+int hvla_generate(hvla_ctx* ctx, const float* tok, const int64_t* mask, const float* cls, int32_t B,
+                  hvla_weights** out, void* stream) {
+  if (!ctx || !out) return HVLA_E_STATE;
+  *out = nullptr;
+  if (!ctx->loaded) FAIL(ctx, HVLA_E_STATE, "hvla_generate before hvla_load_weights");
+  if (B < 1 || B > ctx->cfg.max_batch) FAIL(ctx, HVLA_E_SHAPE, "batch %d outside [1, %d]", B, ctx->cfg.max_batch);
+  if (!tok || !mask || !cls) FAIL(ctx, HVLA_E_SHAPE, "null input pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const PolicyLayout& pl = ctx->lay.pl;
+  const Geom& g = ctx->g;
+  std::unique_ptr<hvla_weights> w(new hvla_weights);
+  w->B = B;
+  hipError_t e = hipSuccess;
+  auto A = [&](DevBuf& b, size_t n) { if (e == hipSuccess) e = b.alloc(n); };
+  A(w->wh, (size_t)B * pl.Gm * 2); A(w->wl, (size_t)B * pl.Gm * 2); A(w->vf, (size_t)B * pl.Gv * 4);
+  A(w->ctx, (size_t)B * g.C * 4);
+  A(w->ring, (size_t)g.horizon * B * g.horizon * g.action_dim * 4); A(w->count, 16);
+  if (e != hipSuccess) FAIL(ctx, HVLA_E_ARENA_FULL, "weight arena for %d episodes: %s", B, hipGetErrorString(e));
+  HIPCHK(ctx, hipMemsetAsync(w->count.p, 0, 16, st));
+  CtxParams cp = ctx->ctxp;
+  cp.tok = tok; cp.attn_mask = mask; cp.cls = cls;
+  cp.ctx = w->ctx.as<float>(); cp.ctx_hi = ctx->ctx_hi.as<__bf16>(); cp.ctx_lo = ctx->ctx_lo.as<__bf16>();
+  HIPCHK(ctx, launch_ctx_encoder(cp, B, st));
+  WeightGenParams wp{ctx->wcat_hi.as<__bf16>(), ctx->wcat_lo.as<__bf16>(), ctx->bcat.as<float>(),
+                     ctx->ctx_hi.as<__bf16>(), ctx->ctx_lo.as<__bf16>(), w->wh.as<__bf16>(), w->wl.as<__bf16>(),
+                     w->vf.as<float>(), B, pl.Gm, pl.Gv, (pl.Gm + pl.Gv) / 32};
+  HIPCHK(ctx, launch_weightgen(wp, g.C, st));
+  *out = w.release();
+  return HVLA_OK;
+}
+
+int hvla_weights_free(hvla_ctx* ctx, hvla_weights* w) {
+  if (!w) return HVLA_OK;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  delete w;
+  return HVLA_OK;
+}
+
+int32_t hvla_weights_batch(const hvla_weights* w) { return w ? w->B : 0; }
+
+int hvla_weights_export(hvla_ctx* ctx, const hvla_weights* w, float* theta, float* context, void* stream) {
+  if (!ctx || !w) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const PolicyLayout& pl = ctx->lay.pl;
+  if (theta)
+    HIPCHK(ctx, launch_export_theta(w->wh.as<__bf16>(), w->wl.as<__bf16>(), w->vf.as<float>(), ctx->perm.as<int32_t>(),
+                                    pl.Gm, pl.Gv, pl.G, w->B, theta, st));
+  if (context)
+    HIPCHK(ctx, hipMemcpyAsync(context, w->ctx.p, (size_t)w->B * ctx->g.C * 4, hipMemcpyDeviceToDevice, st));
+  return HVLA_OK;
+}
+
+static int check_step(hvla_ctx* ctx, int32_t B) {
+  if (!ctx->loaded) FAIL(ctx, HVLA_E_STATE, "called before hvla_load_weights");
+  if (B < 1 || B > ctx->cfg.max_batch) FAIL(ctx, HVLA_E_SHAPE, "batch %d outside [1, %d]", B, ctx->cfg.max_batch);
+  return HVLA_OK;
+}
+
+int hvla_encode(hvla_ctx* ctx, const uint8_t* images, float* tokens, int32_t B, void* stream) {
+  if (!ctx) return HVLA_E_STATE;
+  if (int r = check_step(ctx, B)) return r;
+  if (!images || !tokens) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p};
+  HIPCHK(ctx, launch_encoder(ctx->g, ctx->cfg.enc_dtype, ctx->encw, ws, images, tokens, B,
+                             reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_policy(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float* actions, float* logits, int32_t B,
+                void* stream) {
+  if (!ctx || !w) return HVLA_E_STATE;
+  if (int r = check_step(ctx, B)) return r;
+  if (B != w->B) FAIL(ctx, HVLA_E_SHAPE, "batch %d != arena batch %d", B, w->B);
+  if (!tokens || !actions) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const Geom& g = ctx->g;
+  PolicyParams p{ctx->lay.pl, w->wh.as<__bf16>(), w->wl.as<__bf16>(), w->vf.as<float>(), tokens, actions, logits,
+                 B, g.E, g.P(), g.L, g.M, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
+  HIPCHK(ctx, launch_policy(p, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_step(hvla_ctx* ctx, const hvla_weights* w, const uint8_t* images, float* actions, float* logits, int32_t B,
+              void* stream) {
+  if (!ctx || !w) return HVLA_E_STATE;
+  int r = hvla_encode(ctx, images, ctx->tokens.as<float>(), B, stream);
+  if (r) return r;
+  return hvla_policy(ctx, w, ctx->tokens.as<float>(), actions, logits, B, stream);
+}
+
+int hvla_ensemble_reset(hvla_ctx* ctx, hvla_weights* w, void* stream) {
+  if (!ctx || !w) return HVLA_E_STATE;
+  HIPCHK(ctx, hipMemsetAsync(w->count.p, 0, 16, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const float* mean, const float* std,
+                  const uint8_t* mask, float* out, void* stream) {
+  if (!ctx || !w) return HVLA_E_STATE;
+  if (!actions || !mean || !std || !mask || !out) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, launch_ensemble(actions, w->ring.as<float>(), w->count.as<int>(), mean, std, mask, out, w->B,
+                              ctx->g.horizon, ctx->g.action_dim, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_selftest(hvla_ctx* ctx, void* stream) {
+  if (!ctx) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(ctx, hipMemsetAsync(ctx->flags.p, 0, 64 * sizeof(int), st));
+  HIPCHK(ctx, launch_selftest(ctx->flags.as<int>(), st));
+  int h[64];
+  HIPCHK(ctx, hipMemcpyAsync(h, ctx->flags.p, sizeof h, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  for (int i = 0; i < 8; ++i)
+    if (h[i]) FAIL(ctx, HVLA_E_STATE, "MFMA layout probe %d failed (%d mismatches)", i, h[i]);
+  return HVLA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// common.h — shared device helpers for libhvla (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hvla {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int WAVE = 64;
+
+// ---- 16-bit operand families for the encoder (fp16 default, bf16 selectable) -------------------
+struct OpF16 {
+  using elem = _Float16;
+  using x8 = f16x8;
+  using x4 = f16x4;
+  static __device__ __forceinline__ f32x4 mma16(x8 a, x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mma32(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+struct OpBF16 {
+  using elem = __bf16;
+  using x8 = bf16x8;
+  using x4 = bf16x4;
+  static __device__ __forceinline__ f32x4 mma16(x8 a, x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mma32(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// ---- split-bf16 ("bf16x3") arithmetic: x = hi + lo with hi = bf16(x), lo = bf16(x - hi) ---------
+// a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, f32 accumulate: ~2^-16 relative instead of 2^-9.
+struct Split8 {
+  bf16x8 hi, lo;
+};
+__device__ __forceinline__ void split1(float x, __bf16& h, __bf16& l) {
+  h = (__bf16)x;
+  l = (__bf16)(x - (float)h);
+}
+__device__ __forceinline__ Split8 split8(const float* v) {
+  Split8 s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 h, l;
+    split1(v[j], h, l);
+    s.hi[j] = h;
+    s.lo[j] = l;
+  }
+  return s;
+}
+// 32x32x16: D[32x32] += A[32x16] * B[16x32]
+__device__ __forceinline__ f32x16 mma32_x3(const Split8& a, const Split8& b, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+  return c;
+}
+
+// C-layout of v_mfma_f32_32x32x16_*: lane l holds column (l & 31); register r holds row
+//   crow(r, l >> 5) = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)              (guide §3)
+__device__ __forceinline__ constexpr int crow(int r, int half) {
+  return (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+
+__device__ __forceinline__ float wave_xor_sum32(float v) {
+  // combine the two 32-lane halves (lanes l and l^32)
+  return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+  // flax nn.gelu(approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+}
+
+}  // namespace hvla

@@ -1,0 +1,82 @@
+// kernels.h — parameter blocks + launchers shared between the kernel files and api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layout.h"
+
+namespace hvla {
+
+// ---------------------------------------------------------------- hypernetwork
+struct CtxLayer {
+  const float *ln0_s, *ln0_b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *ln1_s, *ln1_b, *w1, *b1, *w2, *b2;
+};
+constexpr int CTX_MAX_LAYERS = 8;
+struct CtxParams {
+  int T, C, F, heads, layers, lang_dim, E, scale_context;
+  const float* tok;          // [B, T, lang_dim]
+  const int64_t* attn_mask;  // [B, T]
+  const float* cls;          // [B, E]
+  const float *w_tok, *b_tok, *w_img, *b_img, *pos_tok, *pos_img, *pos_layer, *norm_s, *norm_b;
+  CtxLayer layer[CTX_MAX_LAYERS];
+  float* ctx;                // [B, C]
+  __bf16 *ctx_hi, *ctx_lo;   // [B, C]
+};
+struct WeightGenParams {
+  const __bf16 *wcat_hi, *wcat_lo;   // [ntiles][KS][64 lanes][8]
+  const float* bcat;                 // [Gm + Gv]
+  const __bf16 *ctx_hi, *ctx_lo;     // [B, C]
+  __bf16 *wh, *wl;                   // [B, Gm]
+  float* vf;                         // [B, Gv]
+  int B, Gm, Gv, ntiles;
+};
+hipError_t launch_ctx_encoder(const CtxParams& p, int B, hipStream_t st);
+hipError_t launch_weightgen(const WeightGenParams& p, int C, hipStream_t st);
+hipError_t launch_export_theta(const __bf16* wh, const __bf16* wl, const float* vf, const int32_t* perm,
+                               int Gm, int Gv, int G, int B, float* theta, hipStream_t st);
+
+// ---------------------------------------------------------------- image encoder (DINOv2)
+struct EncLayerW {
+  const void *wqkv, *wo, *w1, *w2;               // 16-bit [N][K] (K contiguous)
+  const float *bqkv, *bo, *b1, *b2;              // f32
+  const float *ln1_s, *ln1_b, *ln2_s, *ln2_b, *ls1, *ls2;
+};
+constexpr int ENC_MAX_LAYERS = 24;
+struct EncWeights {
+  const void* w_patch;        // 16-bit [E][Kp] (normalisation folded in)
+  const float* b_patch;       // [E] (bias - sum W mean/std)
+  const float* pos;           // [S, E] position embeddings (row 0 already has cls_token added)
+  const float *lnf_s, *lnf_b;
+  EncLayerW layer[ENC_MAX_LAYERS];
+};
+struct EncWorkspace {
+  float* x;        // [B*S, E] residual stream f32
+  void* h;         // [B*S, E] 16-bit LN output / attention output
+  void* qkv;       // [B*S, 3E] 16-bit
+  void* g;         // [B*S, F] 16-bit MLP hidden; also holds the im2col matrix [B*P, Kp]
+};
+hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const EncWorkspace& ws,
+                          const uint8_t* images, float* tokens, int B, hipStream_t st);
+
+// ---------------------------------------------------------------- generated policy
+struct PolicyParams {
+  PolicyLayout pl;
+  const __bf16 *wh, *wl;     // [B, Gm]
+  const float* vf;           // [B, Gv]
+  const float* tokens;       // [B, P, E]
+  float* actions;            // [B, horizon, action_dim]
+  float* logits;             // [B, horizon] or null
+  int B, E, P, L, M, horizon, action_dim;
+  float tanh_scale, max_action;
+};
+hipError_t launch_policy(const PolicyParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------- caller-side device helpers
+hipError_t launch_ensemble(const float* actions, float* ring, int* count, const float* mean,
+                           const float* std, const uint8_t* mask, float* out, int B, int horizon,
+                           int action_dim, hipStream_t st);
+
+// ---------------------------------------------------------------- self test
+hipError_t launch_selftest(int* fail_flags, hipStream_t st);
+
+}  // namespace hvla

@@ -1,0 +1,171 @@
+"""ctypes binding of libhvla (include/hvla.h).  There is no CPU or eager fallback: if the HIP library
+is missing or the device is not gfx950 every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libhvla.so")
+
+HVLA_ENC_F16, HVLA_ENC_BF16 = 0, 1
+_ERRORS = {-1: "HVLA_E_SHAPE", -2: "HVLA_E_DTYPE", -3: "HVLA_E_DEVICE", -4: "HVLA_E_ARENA_FULL",
+           -5: "HVLA_E_HIP", -6: "HVLA_E_WEIGHTS", -7: "HVLA_E_STATE"}
+
+EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights", "hvla_num_generated",
+           "hvla_generate", "hvla_weights_free", "hvla_weights_batch", "hvla_weights_export",
+           "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
+           "hvla_selftest"]
+
+
+class hvla_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "enc_dim", "enc_layers", "enc_heads",
+                                         "enc_mlp", "dim", "layers", "heads", "mlp", "horizon",
+                                         "action_dim")] + \
+               [("tanh_scale", C.c_float), ("max_action", C.c_float)] + \
+               [(n, C.c_int32) for n in ("ctx_dim", "ctx_layers", "ctx_heads", "ctx_mlp", "lang_tokens",
+                                         "lang_dim", "scale_context", "max_batch", "enc_dtype")]
+
+
+class hvla_tensor_desc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen libhvla.so and declare every prototype of include/hvla.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"libhvla.so not built at {_LIB_PATH}: run `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` (make -C hyper-vla_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.hvla_create.argtypes = [C.POINTER(hvla_config), C.c_int, C.POINTER(vp)]
+    lib.hvla_create.restype = C.c_int
+    lib.hvla_destroy.argtypes = [vp]
+    lib.hvla_destroy.restype = None
+    lib.hvla_last_error.argtypes = [vp]
+    lib.hvla_last_error.restype = C.c_char_p
+    lib.hvla_load_weights.argtypes = [vp, C.POINTER(hvla_tensor_desc), i32]
+    lib.hvla_load_weights.restype = C.c_int
+    lib.hvla_num_generated.argtypes = [vp]
+    lib.hvla_num_generated.restype = i64
+    lib.hvla_generate.argtypes = [vp, vp, vp, vp, i32, C.POINTER(vp), vp]
+    lib.hvla_generate.restype = C.c_int
+    lib.hvla_weights_free.argtypes = [vp, vp]
+    lib.hvla_weights_free.restype = C.c_int
+    lib.hvla_weights_batch.argtypes = [vp]
+    lib.hvla_weights_batch.restype = i32
+    lib.hvla_weights_export.argtypes = [vp, vp, vp, vp, vp]
+    lib.hvla_weights_export.restype = C.c_int
+    lib.hvla_encode.argtypes = [vp, vp, vp, i32, vp]
+    lib.hvla_encode.restype = C.c_int
+    lib.hvla_policy.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    lib.hvla_policy.restype = C.c_int
+    lib.hvla_step.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    lib.hvla_step.restype = C.c_int
+    lib.hvla_ensemble_reset.argtypes = [vp, vp, vp]
+    lib.hvla_ensemble_reset.restype = C.c_int
+    lib.hvla_ensemble.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.hvla_ensemble.restype = C.c_int
+    lib.hvla_selftest.argtypes = [vp, vp]
+    lib.hvla_selftest.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class Context:
+    """One hvla_ctx (one device)."""
+
+    def __init__(self, geometry, device: int = 0, max_batch: int = 256, enc_dtype: str = "f16"):
+        self.lib = load_library()
+        g = geometry
+        if enc_dtype not in ("f16", "bf16"):
+            raise ValueError("enc_dtype must be 'f16' or 'bf16'")
+        self.cfg = hvla_config(g.image_size, g.patch, g.enc_dim, g.enc_layers, g.enc_heads, g.enc_mlp,
+                               g.dim, g.layers, g.heads, g.mlp, g.horizon, g.action_dim,
+                               g.tanh_scale, g.max_action, g.ctx_dim, g.ctx_layers, g.ctx_heads, g.ctx_mlp,
+                               g.lang_tokens, g.lang_dim, int(g.scale_context), int(max_batch),
+                               HVLA_ENC_BF16 if enc_dtype == "bf16" else HVLA_ENC_F16)
+        self.geometry, self.device, self.max_batch, self.enc_dtype = g, device, max_batch, enc_dtype
+        h = C.c_void_p()
+        rc = self.lib.hvla_create(C.byref(self.cfg), device, C.byref(h))
+        if rc != 0:
+            raise NativeError(f"hvla_create failed: {_ERRORS.get(rc, rc)} (geometry outside the hand-written "
+                              f"kernels' specialisation, or device {device} is not a gfx950 GPU)")
+        self.h = h
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.hvla_last_error(self.h)
+            raise NativeError(f"{what}: {_ERRORS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hvla_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_generated(self) -> int:
+        return int(self.lib.hvla_num_generated(self.h))
+
+    def load_weights(self, params: Dict[str, np.ndarray]):
+        keep = []
+        descs = (hvla_tensor_desc * len(params))()
+        for i, (k, v) in enumerate(params.items()):
+            a = np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+            keep.append(a)
+            descs[i] = hvla_tensor_desc(k.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size)
+        self._check(self.lib.hvla_load_weights(self.h, descs, len(params)), "hvla_load_weights")
+
+    def selftest(self, stream: int = 0):
+        self._check(self.lib.hvla_selftest(self.h, C.c_void_p(stream)), "hvla_selftest")
+
+    # raw pointer-level calls (device pointers as ints)
+    def generate(self, tok_ptr, mask_ptr, cls_ptr, B, stream=0):
+        w = C.c_void_p()
+        self._check(self.lib.hvla_generate(self.h, tok_ptr, mask_ptr, cls_ptr, B, C.byref(w), C.c_void_p(stream)),
+                    "hvla_generate")
+        return w
+
+    def weights_free(self, w):
+        self.lib.hvla_weights_free(self.h, w)
+
+    def weights_export(self, w, theta_ptr, ctx_ptr, stream=0):
+        self._check(self.lib.hvla_weights_export(self.h, w, theta_ptr, ctx_ptr, C.c_void_p(stream)), "hvla_weights_export")
+
+    def encode(self, img_ptr, tok_ptr, B, stream=0):
+        self._check(self.lib.hvla_encode(self.h, img_ptr, tok_ptr, B, C.c_void_p(stream)), "hvla_encode")
+
+    def policy(self, w, tok_ptr, act_ptr, logit_ptr, B, stream=0):
+        self._check(self.lib.hvla_policy(self.h, w, tok_ptr, act_ptr, logit_ptr, B, C.c_void_p(stream)), "hvla_policy")
+
+    def step(self, w, img_ptr, act_ptr, logit_ptr, B, stream=0):
+        self._check(self.lib.hvla_step(self.h, w, img_ptr, act_ptr, logit_ptr, B, C.c_void_p(stream)), "hvla_step")
+
+    def ensemble_reset(self, w, stream=0):
+        self._check(self.lib.hvla_ensemble_reset(self.h, w, C.c_void_p(stream)), "hvla_ensemble_reset")
+
+    def ensemble(self, w, act_ptr, mean_ptr, std_ptr, mask_ptr, out_ptr, stream=0):
+        self._check(self.lib.hvla_ensemble(self.h, w, act_ptr, mean_ptr, std_ptr, mask_ptr, out_ptr, C.c_void_p(stream)),
+                    "hvla_ensemble")

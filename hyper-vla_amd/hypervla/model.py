@@ -1,0 +1,255 @@
+"""``hypervla.model.HyperVLA`` — the reference's model API (hypervla/model.py:24-224) hosted on
+libhvla.  Same surface, MI355X-native inside:
+
+    model = HyperVLA.load_pretrained(path, step=None)      # model.py:139-224
+    model = model.replace(params=ema_params)                # flax struct.dataclass .replace
+    base_params, tasks, _ = model.create_tasks(instruction_dict=..., initial_state=...)   # :35-83
+    actions, _ = model.sample_actions(images, instruction_dict, tasks, pad_mask, base_params, rng=key)  # :85-137
+
+Differences a caller can observe, all by design:
+  * ``create_tasks`` accepts B >= 1 episodes (the reference squeezes B == 1, model.py:81) and returns
+    an opaque :class:`GeneratedWeights` handle that owns the device arena; ``.to_pytree()`` gives the
+    reference's ``base_params`` pytree back.
+  * the per-step intermediates (every attention map, base_vit.py:117-118) are not materialised;
+    ``sample_actions`` returns ``{"gripper_logits": ...}`` as its second value.
+  * arrays may be numpy (copied to the device) or torch CUDA tensors (used in place); results come
+    back in the same kind.
+
+There is no CPU / eager fallback: constructing a model without a gfx950 device and a built
+``libhvla.so`` raises.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from . import _native
+from .config import (FULL, Geometry, default_config, generated_leaves, geometry_from_config,
+                     hypernet_param_shapes)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class GeneratedWeights:
+    """Handle to one batch of generated policy weights on the device (what the reference calls
+    ``base_params``).  Immutable from the caller's side; freed on garbage collection."""
+
+    def __init__(self, model: "HyperVLA", handle, batch: int):
+        self._model, self._h, self.batch = model, handle, batch
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                self._model._ctx.weights_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def export(self):
+        """(theta [B, G] in reference leaf order, context embedding [B, C]) as torch CUDA tensors."""
+        torch = _torch()
+        m = self._model
+        dev = m.device
+        theta = torch.empty(self.batch, m._ctx.num_generated, dtype=torch.float32, device=dev)
+        ctx = torch.empty(self.batch, m.geometry.ctx_dim, dtype=torch.float32, device=dev)
+        m._ctx.weights_export(self._h, theta.data_ptr(), ctx.data_ptr(), m._stream())
+        return theta, ctx
+
+    def to_pytree(self, squeeze: bool = False) -> Dict[str, Any]:
+        """The reference's nested ``base_params`` dict (generated leaves only; the shared DINOv2 leaves
+        live once on the device and are not broadcast, hypernetwork.py:233)."""
+        theta = self.export()[0].cpu().numpy()
+        tree: Dict[str, Any] = {}
+        for lf in generated_leaves(self._model.geometry):
+            v = theta[:, lf.offset:lf.offset + lf.size].reshape((self.batch,) + lf.shape)
+            if squeeze:
+                v = v[0]
+            node = tree
+            for key in lf.path[:-1]:
+                node = node.setdefault(key, {})
+            node[lf.path[-1]] = v
+        return tree
+
+
+class HyperVLA:
+    def __init__(self, config: Dict, params: Dict[str, np.ndarray], example_batch: Optional[Dict] = None,
+                 dataset_statistics: Optional[Dict] = None, device: int = 0, max_batch: int = 256,
+                 enc_dtype: str = "f16", _shared_ctx=None):
+        torch = _torch()
+        self.config = config
+        self.params = params
+        self.example_batch = example_batch
+        self.dataset_statistics = dataset_statistics
+        self.geometry: Geometry = geometry_from_config(config)
+        self.base_net_metadata = {"leaves": generated_leaves(self.geometry)}
+        if not torch.cuda.is_available():
+            raise RuntimeError("HyperVLA needs an MI355X (gfx950) device: torch.cuda.is_available() is False "
+                               "and there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.max_batch, self.enc_dtype = max_batch, enc_dtype
+        self._ctx = _native.Context(self.geometry, device, max_batch, enc_dtype)
+        want = hypernet_param_shapes(self.geometry)
+        missing = [k for k in want if k not in params]
+        if missing:
+            raise ValueError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:3]}")
+        self._ctx.load_weights({k: params[k] for k in want})
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def load_pretrained(cls, checkpoint_path: str, step: Optional[int] = None, **kw) -> "HyperVLA":
+        """Reads ``config.json``, ``dataset_statistics.json`` and the parameter file written by
+        :meth:`save_pretrained` (``params_<step>.npz`` / ``params.npz``; flat '/'-joined flax names,
+        SURVEY.md §5.4).  Orbax checkpoints need the JAX-side exporter described in INTEGRATION.md."""
+        with open(os.path.join(checkpoint_path, "config.json")) as f:
+            config = json.load(f)
+        if "action_head_kwargs" not in config["base_net_kwargs"]:        # model.py:157-163
+            config["base_net_kwargs"]["action_head_kwargs"] = dict(
+                token_per_horizon=False, squash_continuous_action=True, clip_target=False, max_action=5.0)
+        stats = None
+        sp = os.path.join(checkpoint_path, "dataset_statistics.json")
+        if os.path.exists(sp):
+            with open(sp) as f:
+                stats = _tree_map(np.array, json.load(f))
+        cands = sorted(p for p in os.listdir(checkpoint_path) if p.startswith("params") and p.endswith(".npz"))
+        if step is not None:
+            cands = [p for p in cands if p == f"params_{step}.npz"]
+        if not cands:
+            raise FileNotFoundError(f"no params*.npz under {checkpoint_path} (step={step})")
+        with np.load(os.path.join(checkpoint_path, cands[-1])) as z:
+            params = {k: z[k] for k in z.files}
+        return cls(config, params, None, stats, **kw)
+
+    def save_pretrained(self, step: int, checkpoint_path: str):
+        os.makedirs(checkpoint_path, exist_ok=True)
+        np.savez(os.path.join(checkpoint_path, f"params_{step}.npz"), **self.params)
+        cp = os.path.join(checkpoint_path, "config.json")
+        if not os.path.exists(cp):
+            with open(cp, "w") as f:
+                json.dump(self.config, f)
+        sp = os.path.join(checkpoint_path, "dataset_statistics.json")
+        if self.dataset_statistics is not None and not os.path.exists(sp):
+            with open(sp, "w") as f:
+                json.dump(_tree_map(lambda x: np.asarray(x).tolist(), self.dataset_statistics), f)
+
+    @classmethod
+    def from_synthetic(cls, geometry: Geometry = FULL, **kw) -> "HyperVLA":
+        from . import synthetic
+        return cls(default_config(geometry), synthetic.synthetic_params(geometry), None,
+                   synthetic.synthetic_dataset_statistics(geometry), **kw)
+
+    def replace(self, **changes) -> "HyperVLA":
+        """flax ``struct.dataclass.replace``: the evaluators swap in EMA params this way
+        (data/simpler/evaluate.py:440-444)."""
+        if set(changes) - {"params", "config", "dataset_statistics", "example_batch"}:
+            raise TypeError(f"cannot replace {set(changes)}")
+        if "params" in changes or "config" in changes:
+            return HyperVLA(changes.get("config", self.config), changes.get("params", self.params),
+                            changes.get("example_batch", self.example_batch),
+                            changes.get("dataset_statistics", self.dataset_statistics),
+                            self.device.index or 0, self.max_batch, self.enc_dtype)
+        import copy
+        other = copy.copy(self)
+        for k, v in changes.items():
+            setattr(other, k, v)
+        return other
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self) -> int:
+        return int(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype):
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(a))).to(device=self.device, dtype=dtype).contiguous()
+
+    # ------------------------------------------------------------------ the hot path
+    def create_tasks(self, goals=None, instruction_dict: Dict = None, initial_state: Dict = None):
+        """hypervla/model.py:35-83.  Returns (base_params handle, tasks dict, intermediates)."""
+        torch = _torch()
+        if instruction_dict is None or initial_state is None:
+            raise ValueError("the built path is language + initial-image conditioned: instruction_dict and "
+                             "initial_state are required (use_initial_image=True, README.md:42)")
+        li = instruction_dict["language_instruction"]
+        g = self.geometry
+        B = int(np.shape(li["input_ids"])[0])
+        tok = self._dev(li["token_embedding"], torch.float32)
+        mask = self._dev(li["attention_mask"], torch.int64)
+        pe = initial_state["patch_embeddings"]
+        cls = self._dev(pe[:, 0] if not isinstance(pe, torch.Tensor) else pe[:, 0], torch.float32)
+        if tuple(tok.shape) != (B, g.lang_tokens, g.lang_dim) or tuple(mask.shape) != (B, g.lang_tokens) \
+                or tuple(cls.shape) != (B, g.enc_dim):
+            raise ValueError(f"bad shapes: token_embedding {tuple(tok.shape)}, attention_mask {tuple(mask.shape)}, "
+                             f"patch_embeddings[:,0] {tuple(cls.shape)} for B={B}")
+        h = self._ctx.generate(tok.data_ptr(), mask.data_ptr(), cls.data_ptr(), B, self._stream())
+        torch.cuda.current_stream(self.device).synchronize()      # inputs may be temporaries
+        tasks = {"pad_mask_dict": {"language_instruction": np.ones(B, dtype=bool)},     # model.py:51-70
+                 "language_instruction": li}
+        return GeneratedWeights(self, h, B), tasks, {}
+
+    def sample_actions(self, images, instruction_dict=None, task=None, timestep_pad_mask=None,
+                       base_params: GeneratedWeights = None, train: bool = False, rng=None,
+                       image_embeddings=None):
+        """hypervla/model.py:85-137.  images uint8 [B, 1, H, W, 3] (or [B, H, W, 3]) -> actions
+        [B, horizon, action_dim]."""
+        torch = _torch()
+        if train:
+            raise NotImplementedError("train=True (dropout / embedding noise) is outside the inference path")
+        if not isinstance(base_params, GeneratedWeights):
+            raise TypeError("base_params must be the handle returned by create_tasks")
+        g = self.geometry
+        as_torch = isinstance(images, torch.Tensor)
+        img = self._dev(images, torch.uint8)
+        if img.dim() == 5:
+            if img.shape[1] != 1:
+                raise ValueError("window size must be 1 (images.squeeze(1), model.py:117)")
+            img = img[:, 0].contiguous()
+        B = base_params.batch
+        if tuple(img.shape) != (B, g.image_size, g.image_size, 3):    # base_vit.py:86-89
+            raise ValueError(f"Input image size must be {g.image_size}x{g.image_size}: got {tuple(img.shape)} for B={B}")
+        actions = torch.empty(B, g.horizon, g.action_dim, dtype=torch.float32, device=self.device)
+        logits = torch.empty(B, g.horizon, dtype=torch.float32, device=self.device)
+        self._ctx.step(base_params._h, img.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, self._stream())
+        if as_torch:
+            return actions, {"gripper_logits": logits}
+        torch.cuda.current_stream(self.device).synchronize()
+        return actions.cpu().numpy(), {"gripper_logits": logits.cpu().numpy()}
+
+    # stage-level entry points (policy-only variant of BASELINE config 2, parity tests)
+    def encode_images(self, images):
+        torch = _torch()
+        g = self.geometry
+        img = self._dev(images, torch.uint8)
+        if img.dim() == 5:
+            img = img[:, 0].contiguous()
+        B = img.shape[0]
+        tokens = torch.empty(B, g.patches, g.enc_dim, dtype=torch.float32, device=self.device)
+        self._ctx.encode(img.data_ptr(), tokens.data_ptr(), B, self._stream())
+        return tokens
+
+    def policy_from_tokens(self, tokens, base_params: GeneratedWeights):
+        torch = _torch()
+        g = self.geometry
+        tok = self._dev(tokens, torch.float32)
+        B = base_params.batch
+        if tuple(tok.shape) != (B, g.patches, g.enc_dim):
+            raise ValueError(f"tokens must be [{B}, {g.patches}, {g.enc_dim}]")
+        actions = torch.empty(B, g.horizon, g.action_dim, dtype=torch.float32, device=self.device)
+        logits = torch.empty(B, g.horizon, dtype=torch.float32, device=self.device)
+        self._ctx.policy(base_params._h, tok.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, self._stream())
+        return actions, logits
+
+
+HyperVLAModel = HyperVLA        # the name BASELINE.json's north_star uses
+
+
+def _tree_map(fn, tree):
+    if isinstance(tree, dict):
+        return {k: _tree_map(fn, v) for k, v in tree.items()}
+    return fn(tree)

@@ -1,0 +1,149 @@
+"""Deterministic synthetic weights and OXE-shaped inputs (no checkpoint / dataset exists offline).
+
+Definitions follow SURVEY.md §8(d) "Synthetic inputs": everything is drawn from
+``numpy.random.Generator(PCG64(seed))`` with seeds fixed here, so the GPU path, the oracle and the
+golden fixtures all see the same numbers.  Every one of the 73 generated leaves is made
+context-dependent (non-zero head kernels) and every bias / LayerNorm parameter is non-trivial so
+that a dropped bias or a swapped scale shows up in parity tests.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .config import (FULL, Geometry, encoder_leaves, generated_leaves, hypernet_param_shapes,
+                     shared_name)
+
+SEED_IMAGES, SEED_TOKENS, SEED_CLS, SEED_STATS, SEED_WEIGHTS = 1000, 2000, 3000, 4000, 5000
+
+
+def _rng(seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _xavier_std(fan_in: int, fan_out: int) -> float:
+    return float(np.sqrt(2.0 / (fan_in + fan_out)))
+
+
+def _leaf_natural(path: Tuple[str, ...], shape: Tuple[int, ...], g: Geometry):
+    """(std of a 'standard init' of this base-net leaf, mean) — the head *bias* is drawn from it."""
+    last = path[-1]
+    if last == "scale":
+        return 0.05, 1.0
+    if last == "bias":
+        return 0.02, 0.0
+    if last == "pos_embedding":
+        return 0.02, 0.0
+    # kernels: xavier over (fan_in, fan_out) of the logical matmul
+    if path[-2] == "out":                       # [H, hd, D]
+        fi, fo = shape[0] * shape[1], shape[2]
+    elif path[-2] in ("query", "key", "value"):  # [D, H, hd]
+        fi, fo = shape[0], shape[1] * shape[2]
+    else:
+        fi, fo = shape[0], shape[1]
+    return _xavier_std(fi, fo), 0.0
+
+
+def synthetic_params(g: Geometry = FULL, seed: int = SEED_WEIGHTS) -> Dict[str, np.ndarray]:
+    """HN checkpoint (reference naming) with float32 leaves."""
+    rng = _rng(seed)
+    shapes = hypernet_param_shapes(g)
+    p: Dict[str, np.ndarray] = {}
+
+    def normal(shape, std, mean=0.0):
+        return (mean + std * rng.standard_normal(shape)).astype(np.float32)
+
+    C = g.ctx_dim
+    p["task_token_projection/kernel"] = normal(shapes["task_token_projection/kernel"],
+                                               _xavier_std(g.lang_dim, C))
+    p["task_token_projection/bias"] = normal((C,), 0.02)
+    p["initial_image_projection/kernel"] = normal(shapes["initial_image_projection/kernel"],
+                                                  _xavier_std(g.enc_dim, C))
+    p["initial_image_projection/bias"] = normal((C,), 0.02)
+    for nm in ("task_pos_embedding", "initial_image_pos_embedding", "layer_pos_embedding"):
+        # layer token is all-zeros + pos-emb (hypernetwork.py:144-145): give it unit scale so the
+        # context embedding is not degenerate
+        p[nm] = normal(shapes[nm], 1.0 if nm == "layer_pos_embedding" else 0.02)
+    for l in range(g.ctx_layers):
+        b = f"Transformer_0/encoderblock_{l}/"
+        for ln in ("LayerNorm_0", "LayerNorm_1"):
+            p[b + ln + "/scale"] = normal((C,), 0.05, 1.0)
+            p[b + ln + "/bias"] = normal((C,), 0.02)
+        a = b + "MultiHeadDotProductAttention_0/"
+        for nm in ("query", "key", "value"):
+            p[a + nm + "/kernel"] = normal(shapes[a + nm + "/kernel"], _xavier_std(C, C))
+            p[a + nm + "/bias"] = normal(shapes[a + nm + "/bias"], 0.02)
+        p[a + "out/kernel"] = normal(shapes[a + "out/kernel"], _xavier_std(C, C))
+        p[a + "out/bias"] = normal((C,), 0.02)
+        p[b + "MlpBlock_0/Dense_0/kernel"] = normal((C, g.ctx_mlp), _xavier_std(C, g.ctx_mlp))
+        p[b + "MlpBlock_0/Dense_0/bias"] = normal((g.ctx_mlp,), 0.02)
+        p[b + "MlpBlock_0/Dense_1/kernel"] = normal((g.ctx_mlp, C), _xavier_std(g.ctx_mlp, C))
+        p[b + "MlpBlock_0/Dense_1/bias"] = normal((C,), 0.02)
+    p["Transformer_0/encoder_norm/scale"] = normal((C,), 0.05, 1.0)
+    p["Transformer_0/encoder_norm/bias"] = normal((C,), 0.02)
+
+    # 73 output heads: bias = a standard init of the base net, kernel = context-dependent delta
+    k_scale = 0.5 / np.sqrt(C) if g.scale_context else 0.5 / C
+    for lf in generated_leaves(g):
+        std, mean = _leaf_natural(lf.path, lf.shape, g)
+        p[lf.head_name + "/bias"] = normal((lf.size,), std, mean)
+        # ctx = LN(.)/sqrt(C) has |ctx|~1 => delta ~ 0.5*std of the leaf's own scale
+        p[lf.head_name + "/kernel"] = normal((C, lf.size), k_scale * std * np.sqrt(C))
+
+    # shared DINOv2 leaves (flat vectors)
+    for path, shape in encoder_leaves(g):
+        last = path[-1]
+        n = int(np.prod(shape))
+        if last == "scale":
+            v = normal((n,), 0.05, 1.0)
+        elif last == "lambda1":
+            v = normal((n,), 0.05, 1.0)
+        elif last == "bias":
+            v = normal((n,), 0.02)
+        else:   # kernels, cls/mask token, position embeddings
+            v = normal((n,), 0.02)
+        p[shared_name(path)] = v
+    assert set(p) == set(shapes)
+    for k, v in p.items():
+        assert v.shape == tuple(shapes[k]), (k, v.shape, shapes[k])
+    return p
+
+
+def synthetic_images(batch: int, g: Geometry = FULL, rank: int = 0) -> np.ndarray:
+    """uint8 [B, 1, H, W, 3] observations (OXE ``image_primary`` with window 1)."""
+    rng = _rng(SEED_IMAGES + rank)
+    return rng.integers(0, 256, size=(batch, 1, g.image_size, g.image_size, 3), dtype=np.uint8)
+
+
+def synthetic_instructions(batch: int, g: Geometry = FULL, rank: int = 0) -> Dict:
+    """``instruction_dict`` as the evaluators build it (data/simpler/evaluate.py:235-254)."""
+    rng = _rng(SEED_TOKENS + rank)
+    emb = (0.2 * rng.standard_normal((batch, g.lang_tokens, g.lang_dim))).astype(np.float32)
+    lo, hi = 3, max(4, min(20, g.lang_tokens))
+    n = rng.integers(lo, hi + 1, size=batch)
+    mask = (np.arange(g.lang_tokens)[None, :] < n[:, None]).astype(np.int64)
+    ids = rng.integers(2, 32000, size=(batch, g.lang_tokens)).astype(np.int64) * mask
+    return {"language_instruction": {"input_ids": ids, "attention_mask": mask,
+                                     "token_embedding": emb}}
+
+
+def synthetic_initial_state(batch: int, g: Geometry = FULL, rank: int = 0) -> Dict:
+    """``initial_state`` with frozen-DINOv2 ``patch_embeddings`` [B, 1+P, E]; only the CLS row is
+    read by the hypernetwork (hypernetwork.py:118-128) so the other rows are left zero."""
+    rng = _rng(SEED_CLS + rank)
+    pe = np.zeros((batch, g.patches + 1, g.enc_dim), np.float32)
+    pe[:, 0] = rng.standard_normal((batch, g.enc_dim)).astype(np.float32)
+    return {"patch_embeddings": pe, "pad_mask_dict": {"image_primary": np.ones((batch, 1))}}
+
+
+def synthetic_dataset_statistics(g: Geometry = FULL) -> Dict:
+    rng = _rng(SEED_STATS)
+    a = g.action_dim
+    mean = (0.1 * rng.standard_normal(a)).astype(np.float32)
+    std = rng.uniform(0.05, 0.5, size=a).astype(np.float32)
+    mask = np.array([True] * (a - 1) + [False])
+    p01 = (mean - 2.3 * std).astype(np.float32)
+    p99 = (mean + 2.3 * std).astype(np.float32)
+    stats = {"action": {"mean": mean, "std": std, "mask": mask, "p01": p01, "p99": p99}}
+    return {"bridge_dataset": stats, "fractal20220817_data": stats, "libero": stats}

@@ -1,0 +1,130 @@
+/*
+ * hvla.h — C ABI of libhvla: the MI355X-native HyperVLA action-prediction path.
+ *
+ * Drop-in boundary.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference repository).  The reference is pure Python/JAX and has no FFI
+ * of its own; a maintainer binds this library with ctypes from hypervla/model.py (the stub is in
+ * INTEGRATION.md; the binding this repo ships is hyper-vla_amd/hypervla/_native.py).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / HIP types in signatures (`stream` is a hipStream_t
+ *     passed as void*; NULL = the device's default stream).
+ *   - every data pointer of generate/encode/policy/step/export is a DEVICE pointer owned by the
+ *     caller; hvla_load_weights takes HOST pointers.
+ *   - every call returns HVLA_OK (0) or a negative HVLA_E_* code; no C++ exception crosses the
+ *     boundary; hvla_last_error(ctx) gives the message of the last failing call on that ctx.
+ *   - a ctx is bound to one device; calls on one ctx are not re-entrant; different ctxs are
+ *     independent.  After hvla_load_weights, generate/encode/policy/step do not allocate, do not
+ *     synchronise and launch only on `stream`, so a step can be captured into a hipGraph.
+ */
+#ifndef HVLA_H_
+#define HVLA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVLA_OK 0
+#define HVLA_E_SHAPE (-1)      /* batch / geometry outside what the ctx was created for        */
+#define HVLA_E_DTYPE (-2)      /* unsupported operand type selector                            */
+#define HVLA_E_DEVICE (-3)     /* bad device ordinal, or not a gfx950 device                   */
+#define HVLA_E_ARENA_FULL (-4) /* device allocation for a weight arena / workspace failed      */
+#define HVLA_E_HIP (-5)        /* a HIP runtime call failed (message has the hipError string)  */
+#define HVLA_E_WEIGHTS (-6)    /* missing / mis-sized / unknown named tensor                   */
+#define HVLA_E_STATE (-7)      /* call order violated (e.g. step before load_weights)          */
+
+#define HVLA_ENC_F16 0  /* encoder MFMA operands fp16 (default: meets the 1e-3 action tolerance) */
+#define HVLA_ENC_BF16 1 /* encoder MFMA operands bf16 (same rate, ~7x larger action error)       */
+
+typedef struct hvla_ctx hvla_ctx;
+typedef struct hvla_weights hvla_weights; /* per-batch generated-weight arena (opaque)          */
+
+/* Geometry of the path == the values the reference reads from config.json
+ * (hypervla/model.py:152-163,197-200; README.md:33-61).                                        */
+typedef struct hvla_config {
+  int32_t image_size, patch;                 /* 224, 14                                         */
+  int32_t enc_dim, enc_layers, enc_heads, enc_mlp; /* DINOv2-base: 768, 12, 12, 3072            */
+  int32_t dim, layers, heads, mlp;           /* generated vit_t: 64, 4, 4, 128                  */
+  int32_t horizon, action_dim;               /* 4, 7                                            */
+  float tanh_scale, max_action;              /* 5, 5 (action_heads.py:469-470)                  */
+  int32_t ctx_dim, ctx_layers, ctx_heads, ctx_mlp; /* hypernet: 128, 6, 4, 512                  */
+  int32_t lang_tokens, lang_dim;             /* 32, 768                                         */
+  int32_t scale_context;                     /* hypernetwork.py:191-192                         */
+  int32_t max_batch;                         /* workspace is sized for this many episodes       */
+  int32_t enc_dtype;                         /* HVLA_ENC_F16 | HVLA_ENC_BF16                    */
+} hvla_config;
+
+/* One named float32 tensor of the hypernetwork checkpoint, HOST memory, reference naming
+ * (SURVEY.md §5.4): "task_token_projection/kernel", "Transformer_0/encoderblock_3/LayerNorm_0/scale",
+ * "output_head_<flat leaf>/kernel", flat shared vectors "encoder_image_encoder_<path>", ...      */
+typedef struct hvla_tensor_desc {
+  const char* name;
+  const float* data;
+  int64_t numel;
+} hvla_tensor_desc;
+
+/* Replaces: HyperVLA.load_pretrained's model construction (hypervla/model.py:197-208).          */
+int hvla_create(const hvla_config* cfg, int device, hvla_ctx** out);
+void hvla_destroy(hvla_ctx* ctx);
+const char* hvla_last_error(const hvla_ctx* ctx);
+
+/* Replaces: orbax restore of HN params + `.replace(params=EMA)` (hypervla/model.py:210-214,
+ * data/simpler/evaluate.py:438-444).  Packs every tensor into its device layout.
+ * Must be given every tensor of the checkpoint in one call; may be called again to swap weights. */
+int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* tensors, int32_t n);
+
+/* Number of generated parameters per episode (G = 201500 for the README geometry).              */
+int64_t hvla_num_generated(const hvla_ctx* ctx);
+
+/* Replaces: HyperVLA.create_tasks -> HyperNetwork.__call__ (hypervla/model.py:35-83,
+ * hypervla/components/hypernetwork.py:99-233) for B episodes at once.
+ *   token_embedding f32 [B, lang_tokens, lang_dim]; attention_mask i64 [B, lang_tokens];
+ *   initial_cls f32 [B, enc_dim]  (= initial_state["patch_embeddings"][:, 0]).
+ * On success *out owns a device arena with B episodes' policy weights.                          */
+int hvla_generate(hvla_ctx* ctx, const float* token_embedding, const int64_t* attention_mask,
+                  const float* initial_cls, int32_t B, hvla_weights** out, void* stream);
+int hvla_weights_free(hvla_ctx* ctx, hvla_weights* w);
+int32_t hvla_weights_batch(const hvla_weights* w);
+
+/* Reference-order views for the caller / parity tests (the reference returns these from
+ * create_tasks as `base_params` and the context embedding).  theta f32 [B, G] in pytree leaf
+ * order; context f32 [B, ctx_dim].  Either pointer may be NULL.          */
+int hvla_weights_export(hvla_ctx* ctx, const hvla_weights* w, float* theta, float* context,
+                        void* stream);
+
+/* Replaces: ViT.__call__'s DINOv2 branch up to `last_hidden_state[:, 1:]`
+ * (hypervla/components/base_vit.py:109-122).  images u8 [B, H, W, 3] -> tokens f32 [B, P, E].   */
+int hvla_encode(hvla_ctx* ctx, const uint8_t* images, float* tokens, int32_t B, void* stream);
+
+/* Replaces: the rest of BaseNetwork.predict_action with per-episode weights
+ * (base_vit.py:130-227, transformer.py:127-262, action_heads.py:431-472,524-538).
+ *   tokens f32 [B, P, E] -> actions f32 [B, horizon, action_dim]; gripper_logits f32 [B, horizon]
+ *   (nullable; the threshold `logit >= 0` is what column action_dim-1 of `actions` holds).     */
+int hvla_policy(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float* actions,
+                float* gripper_logits, int32_t B, void* stream);
+
+/* Replaces: HyperVLA.sample_actions (hypervla/model.py:85-137): hvla_encode + hvla_policy through
+ * the ctx's own token workspace.  B must equal hvla_weights_batch(w).                           */
+int hvla_step(hvla_ctx* ctx, const hvla_weights* w, const uint8_t* images, float* actions,
+              float* gripper_logits, int32_t B, void* stream);
+
+/* Replaces: the un-normalise + temporal ensemble of InferenceWrapper.step for a batch of
+ * episodes (data/utils/hypervla_interface.py:219-253, data/utils/action_ensemble.py:15-27,
+ * temperature 0).  Keeps a device ring of the last `horizon` predictions inside `w`.
+ *   actions f32 [B, horizon, action_dim] (as written by hvla_policy/step);
+ *   mean/std f32 [action_dim], mask u8 [action_dim] (device); out f32 [B, action_dim].          */
+int hvla_ensemble_reset(hvla_ctx* ctx, hvla_weights* w, void* stream);
+int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const float* mean,
+                  const float* std, const uint8_t* mask, float* out, void* stream);
+
+/* Primitive self-check used by tests: runs the MFMA fragment-layout probes on the ctx's device
+ * and returns HVLA_OK only if every probe matches its exact integer expectation.                */
+int hvla_selftest(hvla_ctx* ctx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVLA_H_ */
