@@ -1,0 +1,192 @@
+"""bench.py — headline benchmark of the HyperVLA action-prediction path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--batch 256] [--enc-dtype f16|bf16]
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one `sample_actions` over one batch of synthetic OXE-shaped observations: uint8 224x224
+images -> DINOv2-base (in the loop, as the reference runs it, base_vit.py:109-133) -> generated vit_t
+policy -> [4, 7] action chunks.  1 action = 1 sample-step.  The hypernetwork (`create_tasks`) runs once
+per episode batch before the timed region (BASELINE.json configs[1]: "weight-gen once + vit_t inference,
+batch 256"); images are resident in HBM when timing starts.  Episodes shard across ranks with no
+data-path collective => weak scaling, value = sum of per-rank actions / max rank time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "hyper-vla_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+
+
+def algorithmic_flops(g):
+    """Per sample-step, counted as the reference executes them (SURVEY.md §8d / BASELINE.md §2)."""
+    S, E, F, P, D, M, L = g.seq, g.enc_dim, g.enc_mlp, g.patches, g.dim, g.mlp, g.layers
+    enc_linear = g.enc_layers * 2 * S * (4 * E * E + 2 * E * F)
+    enc_attn = g.enc_layers * 4 * S * S * E
+    patch = 2 * P * g.patch_in * E
+    pol = 2 * P * E * D + L * 2 * S * (4 * D * D + 2 * D * M) + L * 4 * S * S * D + 2 * D * (g.horizon * g.action_dim)
+    return dict(encoder=enc_linear + enc_attn + patch, policy=pol, fc1=2 * S * E * F)
+
+
+def cpu_baseline(g, params, seconds=12.0, batch=8):
+    """The float32 torch-CPU restatement of the same step (oracle/hvla_ref_torch.py, "port"; JAX itself
+    is not installable here), timed on this host's cores on a bounded sample."""
+    from hypervla import synthetic as syn
+    from hypervla.config import encoder_leaves, generated_leaves
+    from oracle import hvla_ref_torch as ot
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ref = ot.FullRef(params, g, generated_leaves(g), dict(encoder_leaves(g)), torch.float32)
+    ins, st, im = syn.synthetic_instructions(batch, g), syn.synthetic_initial_state(batch, g), syn.synthetic_images(batch, g)
+    theta, _ = ref.create_tasks(ins, st)
+    ref.sample_actions(theta, im)                       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ref.sample_actions(theta, im)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 2:
+            break
+    return {"value": round(batch * n / dt, 3), "unit": "actions/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {batch} (same workload, f32 torch-CPU restatement of the JAX graph, "
+                      f"{dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="episodes per GPU")
+    ap.add_argument("--enc-dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # RCCL; used only for barrier + max(time)
+
+    from hypervla import synthetic as syn
+    from hypervla.config import FULL
+    from hypervla.model import HyperVLA
+    g, B = FULL, a.batch
+    model = HyperVLA.from_synthetic(g, device=local, max_batch=B, enc_dtype=a.enc_dtype)
+    dev = model.device
+    ins, st = syn.synthetic_instructions(B, g, rank), syn.synthetic_initial_state(B, g, rank)
+    images = torch.as_tensor(syn.synthetic_images(B, g, rank)[:, 0]).to(dev).contiguous()   # resident in HBM
+    ctx = model._ctx
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    t0 = time.perf_counter()
+    w, tasks, _ = model.create_tasks(instruction_dict=ins, initial_state=st)      # once per episode batch
+    torch.cuda.synchronize(dev)
+    generate_ms = (time.perf_counter() - t0) * 1e3
+    actions = torch.empty(B, g.horizon, g.action_dim, device=dev)
+    logits = torch.empty(B, g.horizon, device=dev)
+    stream = model._stream()
+
+    def step():
+        ctx.step(w._h, images.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, stream)
+
+    for _ in range(a.warmup):
+        step()
+    ctx.profile(1)                     # HIP events around the dominant kernel only, on the launch stream
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    dom = ctx.profile_read()["fc1_gemm"]
+    ctx.profile(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- per-step latency distribution + full kernel breakdown (separate, un-timed passes)
+    lat = []
+    for _ in range(min(a.steps, 20)):
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize(dev)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    ctx.profile(2)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(dev)
+    br = ctx.profile_read()
+    ctx.profile(0)
+    breakdown = {k: round(v[0] / 3, 4) for k, v in br.items()}
+
+    # policy-only variant (patch tokens resident -> actions), BASELINE config 2 "(P)"
+    tokens = model.encode_images(images)
+    torch.cuda.synchronize(dev)
+    for _ in range(3):
+        ctx.policy(w._h, tokens.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, stream)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(20):
+        ctx.policy(w._h, tokens.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, stream)
+    torch.cuda.synchronize(dev)
+    pol_ms = (time.perf_counter() - t1) * 1e3 / 20
+
+    fl = algorithmic_flops(g)
+    dom_ms = dom[0] / max(dom[1], 1)
+    achieved = fl["fc1"] * B / (dom_ms * 1e-3) / 1e12
+    ms_per_step = elapsed / a.steps * 1e3
+    out = {
+        "metric": "actions_per_sec", "value": round(world * B * a.steps / elapsed, 2), "unit": "actions/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.enc_dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: hypernet weight-gen once (untimed) + full sample_actions step "
+                               "(u8 224x224 -> DINOv2-base E=768 in the loop -> generated vit_t 4L/64d policy -> "
+                               "[4,7] action chunk); 1 action = 1 sample-step",
+                   "batch_per_gpu": B, "global_batch": world * B, "encoder": "DINOv2-base (reference parity, E=768)",
+                   "parallelism": f"episode-dp{world} (no collectives)",
+                   "encoder_operands": a.enc_dtype, "policy_operands": "split-bf16 (bf16x3)"},
+        "p50_step_latency_ms": round(float(np.median(lat)), 4),
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<Op,EPI_GELU> (encoder fc1: [B*257,768]x[768,3072] + bias + erf-GELU)",
+                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                     "launch_ms": round(dom_ms, 4), "launches_timed": dom[1],
+                     "flops_per_launch": fl["fc1"] * B},
+        "step_tflops": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12, 2),
+        "step_frac_of_peak": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
+        "kernel_ms_per_step": breakdown,
+        "policy_only": {"ms_per_step": round(pol_ms, 4), "actions_per_sec": round(B / (pol_ms * 1e-3), 1),
+                        "input": "f32 patch tokens [B,256,768] resident in HBM"},
+        "generate_ms": round(generate_ms, 3),
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(g, model.params)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

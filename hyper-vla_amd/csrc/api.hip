@@ -72,6 +72,7 @@ struct hvla_ctx {
   EncWeights encw{};
   // workspaces (sized for cfg.max_batch)
   DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, tokens, flags;
+  Profiler prof;
 };
 
 #define FAIL(ctx, code, ...)                       \
@@ -119,7 +120,7 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   if (!ok) return c->enc_dtype != HVLA_ENC_F16 && c->enc_dtype != HVLA_ENC_BF16 ? HVLA_E_DTYPE : HVLA_E_SHAPE;
   if (hipSetDevice(device) != hipSuccess) return HVLA_E_DEVICE;
   ctx->lay = build_layout(g);
-  ctx->Kp = (g.patch * g.patch * 3 + 63) / 64 * 64;
+  ctx->Kp = 2 * ((g.patch * g.patch * 3 + 63) / 64 * 64);     // [W_hi | W_lo] along K (encoder.hip)
   {  // the packed order must be a bijection onto the reference parameter vector
     std::vector<uint8_t> seen(ctx->lay.pl.G, 0);
     for (int32_t r : ctx->lay.perm)
@@ -307,21 +308,32 @@ int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
     std::vector<size_t> off16, offf;
     auto mark16 = [&](size_t n) { off16.push_back(o16); o16 += n; };
     auto markf = [&](size_t n) { offf.push_back(of); of += n; };
-    // patch embedding: fold (x/255 - mean)/std; weights stored x256 so small values keep 16-bit precision
+    // patch embedding: ((p/255 - mean)/std) . w  ==  (p - 128) . w' / 256 + const with w' = 256 w / (255 std)
+    // (x256 keeps small weights in the 16-bit normal range); w' is stored split [hi | lo] along K.
     const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
+    const int Kp1 = Kp / 2;
     mark16((size_t)E * Kp);
     markf(E);
+    auto back = [&](uint16_t h) -> float {
+      if (bf) return bf2f(h);
+      _Float16 x;
+      memcpy(&x, &h, 2);
+      return (float)x;
+    };
     for (int nn = 0; nn < E; ++nn) {
       double bacc = e_pb[nn];
-      for (int k = 0; k < Kp; ++k) {
-        float w = 0.f;
+      for (int k = 0; k < Kp1; ++k) {
+        uint16_t hi = 0, lo = 0;
         if (k < Kreal) {
           const int c = k % 3;
           const double wk = e_pk[(size_t)k * E + nn];
-          w = (float)(wk * 256.0 / (255.0 * sd[c]));
-          bacc -= wk * mean[c] / sd[c];
+          const float w = (float)(wk * 256.0 / (255.0 * sd[c]));
+          hi = cv(w);
+          lo = cv(w - back(hi));
+          bacc += wk * (128.0 / 255.0 - mean[c]) / sd[c];
         }
-        w16[off16.back() + (size_t)nn * Kp + k] = cv(w);
+        w16[off16.back() + (size_t)nn * Kp + k] = hi;
+        w16[off16.back() + (size_t)nn * Kp + Kp1 + k] = lo;
       }
       wf[offf.back() + nn] = (float)bacc;
     }
@@ -441,7 +453,7 @@ int hvla_encode(hvla_ctx* ctx, const uint8_t* images, float* tokens, int32_t B, 
   HIPCHK(ctx, hipSetDevice(ctx->device));
   EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p};
   HIPCHK(ctx, launch_encoder(ctx->g, ctx->cfg.enc_dtype, ctx->encw, ws, images, tokens, B,
-                             reinterpret_cast<hipStream_t>(stream)));
+                             reinterpret_cast<hipStream_t>(stream), &ctx->prof));
   return HVLA_OK;
 }
 
@@ -455,7 +467,9 @@ int hvla_policy(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float
   const Geom& g = ctx->g;
   PolicyParams p{ctx->lay.pl, w->wh.as<__bf16>(), w->wl.as<__bf16>(), w->vf.as<float>(), tokens, actions, logits,
                  B, g.E, g.P(), g.L, g.M, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
+  ctx->prof.begin(HVLA_PROF_POLICY, reinterpret_cast<hipStream_t>(stream));
   HIPCHK(ctx, launch_policy(p, reinterpret_cast<hipStream_t>(stream)));
+  ctx->prof.end(HVLA_PROF_POLICY, reinterpret_cast<hipStream_t>(stream));
   return HVLA_OK;
 }
 
@@ -480,6 +494,29 @@ int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const fl
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, launch_ensemble(actions, w->ring.as<float>(), w->count.as<int>(), mean, std, mask, out, w->B,
                               ctx->g.horizon, ctx->g.action_dim, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_profile(hvla_ctx* ctx, int32_t mode) {
+  if (!ctx) return HVLA_E_STATE;
+  if (mode < 0 || mode > 2) FAIL(ctx, HVLA_E_SHAPE, "profile mode %d", mode);
+  ctx->prof.mode = mode;
+  return HVLA_OK;
+}
+
+int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches) {
+  if (!ctx || !ms || !launches) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < HVLA_PROF_N; ++i) ms[i] = 0.f, launches[i] = 0;
+  Profiler& p = ctx->prof;
+  for (size_t i = 0; i < p.used; ++i) {
+    HIPCHK(ctx, hipEventSynchronize(p.stop[i]));
+    float t = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&t, p.start[i], p.stop[i]));
+    ms[p.cat[i]] += t;
+    launches[p.cat[i]] += 1;
+  }
+  p.used = 0;
   return HVLA_OK;
 }
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "layout.h"
 
 namespace hvla {
@@ -55,8 +57,31 @@ struct EncWorkspace {
   void* qkv;       // [B*S, 3E] 16-bit
   void* g;         // [B*S, F] 16-bit MLP hidden; also holds the im2col matrix [B*P, Kp]
 };
+// optional live timing: a pool of hipEvent pairs tagged with a category (include/hvla.h HVLA_PROF_*)
+struct Profiler {
+  int mode = 0;                       // 0 off, 1 dominant kernel only, 2 all
+  std::vector<hipEvent_t> start, stop;
+  std::vector<int> cat;
+  size_t used = 0;
+  bool want(int c) const { return mode == 2 || (mode == 1 && c == 5); }
+  void begin(int c, hipStream_t st) {
+    if (!want(c)) return;
+    if (used == start.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      start.push_back(a), stop.push_back(b), cat.push_back(c);
+    }
+    cat[used] = c;
+    (void)hipEventRecord(start[used], st);
+  }
+  void end(int c, hipStream_t st) {
+    if (!want(c) || used >= start.size()) return;
+    (void)hipEventRecord(stop[used], st);
+    ++used;
+  }
+};
 hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const EncWorkspace& ws,
-                          const uint8_t* images, float* tokens, int B, hipStream_t st);
+                          const uint8_t* images, float* tokens, int B, hipStream_t st, Profiler* prof);
 
 // ---------------------------------------------------------------- generated policy
 struct PolicyParams {

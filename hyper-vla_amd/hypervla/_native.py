@@ -17,7 +17,8 @@ _ERRORS = {-1: "HVLA_E_SHAPE", -2: "HVLA_E_DTYPE", -3: "HVLA_E_DEVICE", -4: "HVL
 EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights", "hvla_num_generated",
            "hvla_generate", "hvla_weights_free", "hvla_weights_batch", "hvla_weights_export",
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
-           "hvla_selftest"]
+           "hvla_selftest", "hvla_profile", "hvla_profile_read"]
+PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy"]
 
 
 class hvla_config(C.Structure):
@@ -78,6 +79,10 @@ def load_library():
     lib.hvla_ensemble_reset.restype = C.c_int
     lib.hvla_ensemble.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.hvla_ensemble.restype = C.c_int
+    lib.hvla_profile.argtypes = [vp, i32]
+    lib.hvla_profile.restype = C.c_int
+    lib.hvla_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
+    lib.hvla_profile_read.restype = C.c_int
     lib.hvla_selftest.argtypes = [vp, vp]
     lib.hvla_selftest.restype = C.c_int
     _lib = lib
@@ -140,6 +145,16 @@ class Context:
 
     def selftest(self, stream: int = 0):
         self._check(self.lib.hvla_selftest(self.h, C.c_void_p(stream)), "hvla_selftest")
+
+    def profile(self, mode: int):
+        self._check(self.lib.hvla_profile(self.h, mode), "hvla_profile")
+
+    def profile_read(self):
+        """{category: (total ms, launches)} since the last read."""
+        ms = (C.c_float * len(PROF_NAMES))()
+        n = (C.c_int32 * len(PROF_NAMES))()
+        self._check(self.lib.hvla_profile_read(self.h, ms, n), "hvla_profile_read")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(PROF_NAMES)}
 
     # raw pointer-level calls (device pointers as ints)
     def generate(self, tok_ptr, mask_ptr, cls_ptr, B, stream=0):

@@ -76,6 +76,10 @@ class Geometry:
 FULL = Geometry()
 # DINOv2-small token width named by BASELINE.json config 2 (policy-only variant)
 SMALL_E = Geometry(enc_dim=384, enc_heads=6, enc_mlp=1536)
+# Reduced geometry inside the HIP kernels' specialisation (P % 32 == 0, encoder head_dim 64, policy
+# 64-d / 4 heads): fast full-tensor GPU parity runs against the live oracle
+MID = Geometry(image_size=112, patch=14, enc_dim=128, enc_layers=2, enc_heads=2, enc_mlp=512,
+               layers=2, ctx_layers=2, ctx_mlp=256, lang_tokens=12, lang_dim=64)
 # A tiny geometry that still walks every code path (used for exhaustive intermediate fixtures)
 TINY = Geometry(image_size=56, patch=14, enc_dim=32, enc_layers=2, enc_heads=2, enc_mlp=64,
                 dim=16, layers=2, heads=2, mlp=32, ctx_dim=16, ctx_layers=2, ctx_heads=2, ctx_mlp=32,

@@ -120,6 +120,22 @@ int hvla_ensemble_reset(hvla_ctx* ctx, hvla_weights* w, void* stream);
 int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const float* mean,
                   const float* std, const uint8_t* mask, float* out, void* stream);
 
+/* Live per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ *   mode 0: off (default);  1: only the dominant kernel (encoder fc1 GEMM);  2: every category.
+ * hvla_profile_read synchronises the recorded events, adds their durations per category into
+ * ms[HVLA_PROF_N] / launches[HVLA_PROF_N], and clears the event pool.                            */
+#define HVLA_PROF_PATCH 0   /* im2col + patch-embedding GEMM + CLS rows */
+#define HVLA_PROF_LN 1      /* encoder LayerNorms                       */
+#define HVLA_PROF_QKV 2     /* encoder QKV GEMM                         */
+#define HVLA_PROF_ATTN 3    /* encoder attention                        */
+#define HVLA_PROF_OUT 4     /* encoder out-projection GEMM (+residual)  */
+#define HVLA_PROF_FC1 5     /* encoder fc1 GEMM (+erf GELU)             */
+#define HVLA_PROF_FC2 6     /* encoder fc2 GEMM (+residual)             */
+#define HVLA_PROF_POLICY 7  /* generated-policy megakernel              */
+#define HVLA_PROF_N 8
+int hvla_profile(hvla_ctx* ctx, int32_t mode);
+int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches);
+
 /* Primitive self-check used by tests: runs the MFMA fragment-layout probes on the ctx's device
  * and returns HVLA_OK only if every probe matches its exact integer expectation.                */
 int hvla_selftest(hvla_ctx* ctx, void* stream);

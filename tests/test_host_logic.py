@@ -1,0 +1,124 @@
+"""CPU: host-side mirror of the reference interface (config, leaf metadata, wrapper post-processing)."""
+import json
+
+import numpy as np
+import pytest
+
+from hypervla import synthetic as syn
+from hypervla.config import (FULL, MID, SMALL_E, TINY, default_config, encoder_leaves, generated_leaves,
+                             geometry_from_config, hypernet_param_shapes, total_generated)
+from hypervla.interface import ActionEnsembler, InferenceWrapper, euler2axangle
+from oracle import hvla_ref_np as onp
+
+
+def test_leaf_table_matches_survey_appendix_b():
+    lv = generated_leaves(FULL)
+    assert len(lv) == 73 and total_generated(FULL) == 201_500
+    names = [l.flat_name for l in lv]
+    assert names == sorted(names, key=lambda n: [p for p in lv if p.flat_name == n][0].path)   # pytree order
+    per_block = sum(l.size for l in lv if "encoderblock_2" in l.flat_name)
+    assert per_block == 33_472
+    assert lv[-1].flat_name == "encoder_pos_embedding" and lv[-1].shape == (1, 257, 64)
+    assert lv[0].head_name == "output_head_action_head_continuous_head_bias"
+    assert total_generated(SMALL_E) == 201_500 - 384 * 64
+    n_enc = sum(int(np.prod(s)) for _, s in encoder_leaves(FULL))
+    assert 85_000_000 < n_enc < 87_000_000       # 86.6 M with the un-baked 37x37 pos-emb
+
+
+def test_config_roundtrip_and_rejections():
+    for g in (FULL, MID, TINY, SMALL_E):
+        cfg = json.loads(json.dumps(default_config(g)))
+        assert geometry_from_config(cfg) == g
+    cfg = default_config(FULL)
+    cfg["base_net_kwargs"]["action_head_type"] = "diffusion"
+    with pytest.raises(ValueError):
+        geometry_from_config(cfg)
+    cfg = default_config(FULL)
+    cfg["hypernet_kwargs"]["share_layer_index"] = False
+    with pytest.raises(ValueError):
+        geometry_from_config(cfg)
+
+
+def test_synthetic_params_cover_checkpoint_schema():
+    p = syn.synthetic_params(TINY)
+    shapes = hypernet_param_shapes(TINY)
+    assert set(p) == set(shapes)
+    assert all(p[k].dtype == np.float32 and p[k].shape == tuple(shapes[k]) for k in p)
+    q = syn.synthetic_params(TINY)
+    assert all(np.array_equal(p[k], q[k]) for k in p)                       # deterministic
+
+
+def test_euler2axangle_against_rotation_matrices():
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        r, pch, y = rng.uniform(-1.5, 1.5, 3)
+        ax, ang = euler2axangle(r, pch, y)
+        ax2, ang2 = onp.euler2axangle(r, pch, y)
+        np.testing.assert_allclose(ax * ang, ax2 * ang2, atol=1e-12)
+        cx, sx, cy, sy, cz, sz = np.cos(r), np.sin(r), np.cos(pch), np.sin(pch), np.cos(y), np.sin(y)
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        R = Rz @ Ry @ Rx                                                       # static xyz
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rod = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        np.testing.assert_allclose(Rod, R, atol=1e-12)
+    assert euler2axangle(0.0, 0.0, 0.0)[1] == 0.0
+
+
+class _FakeModel:
+    """create_tasks / sample_actions stand-in so the wrapper's host logic runs without a GPU."""
+
+    def __init__(self, raw):
+        self.raw, self.t = raw, 0
+        self.config = default_config(FULL)
+        self.dataset_statistics = syn.synthetic_dataset_statistics(FULL)
+
+    def create_tasks(self, instruction_dict=None, initial_state=None):
+        self.t = 0
+        return object(), {"language_instruction": instruction_dict}, {}
+
+    def sample_actions(self, images, instruction_dict, task, pad_mask, base_params, rng=None, image_embeddings=None):
+        assert images.shape == (1, 1, 224, 224, 3) and images.dtype == np.uint8 and pad_mask.shape == (1, 1)
+        a = self.raw[self.t][None]
+        self.t += 1
+        return a, {}
+
+
+@pytest.mark.parametrize("setup", ["google_robot", "widowx_bridge", "libero"])
+@pytest.mark.parametrize("ens", [True, False])
+def test_wrapper_chain_matches_golden(golden_dir, setup, ens):
+    z = np.load(golden_dir + "/wrapper.npz")
+    raw = z["raw_actions"]
+    w = InferenceWrapper(_FakeModel(raw), policy_setup=setup, horizon=1, pred_action_horizon=4, image_size=224,
+                         action_ensemble=ens)
+    w.reset("task", {"language_instruction": {}}, {"patch_embeddings": None})
+    img = np.zeros((224, 224, 3), np.uint8)
+    raws, acts = [], []
+    for t in range(len(raw)):
+        ra, act, im, (desc, task), dt = w.step(img)
+        raws.append(ra), acts.append(act)
+    np.testing.assert_allclose(np.stack(raws), z[f"{setup}_{int(ens)}_raw"], atol=1e-12)
+    np.testing.assert_allclose(np.stack(acts), z[f"{setup}_{int(ens)}_act"], atol=1e-6)
+    if setup == "google_robot" and not ens:
+        assert (np.abs(np.stack(acts)[:, -1]) > 0.5).sum() >= 15             # sticky gripper exercised
+
+
+def test_wrapper_rejects_unresized_frames_and_bad_setup():
+    m = _FakeModel(np.zeros((1, 4, 7)))
+    with pytest.raises(ValueError):
+        InferenceWrapper(m, policy_setup="metaworld")
+    w = InferenceWrapper(m, policy_setup="libero", pred_action_horizon=4, image_size=224)
+    w.reset("t", {"language_instruction": {}}, {})
+    with pytest.raises(NotImplementedError):
+        w.step(np.zeros((480, 640, 3), np.uint8))
+
+
+def test_batched_ensembler_equals_unbatched():
+    rng = np.random.default_rng(2)
+    a, b = ActionEnsembler(4), [ActionEnsembler(4) for _ in range(3)]
+    for t in range(6):
+        x = rng.normal(size=(3, 4, 7))
+        got = a.ensemble_action(x)
+        for i in range(3):
+            np.testing.assert_allclose(got[i], b[i].ensemble_action(x[i]), atol=1e-12)

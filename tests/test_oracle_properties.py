@@ -1,0 +1,100 @@
+"""CPU: invariants the reference *code* guarantees (SURVEY.md §8c pin 3), checked on the oracle."""
+import numpy as np
+
+from hypervla import synthetic as syn
+from hypervla.config import TINY, encoder_leaves, generated_leaves
+from oracle import hvla_ref_np as onp
+
+G = TINY
+LEAVES, ENC = generated_leaves(G), dict(encoder_leaves(G))
+
+
+def _inputs(B=3):
+    return (syn.synthetic_params(G), syn.synthetic_instructions(B, G), syn.synthetic_initial_state(B, G),
+            syn.synthetic_images(B, G))
+
+
+def test_zero_kernel_gives_head_bias_for_any_context():
+    """hypernetwork.py:75-77 + model.py:330-346: with zero head kernels the generated params are the bias."""
+    P, ins, st, _ = _inputs()
+    for lf in LEAVES:
+        P[lf.head_name + "/kernel"] = np.zeros_like(P[lf.head_name + "/kernel"])
+    bp, _ = onp.create_tasks(P, G, LEAVES, ins, st)
+    for lf in LEAVES:
+        want = np.broadcast_to(P[lf.head_name + "/bias"].reshape(lf.shape), bp[lf.flat_name].shape)
+        np.testing.assert_array_equal(bp[lf.flat_name], want)
+
+
+def test_padded_language_tokens_cannot_influence_context():
+    """hypernetwork.py:151-157 (attend_to_padding=False)."""
+    P, ins, st, _ = _inputs()
+    li = ins["language_instruction"]
+    c0 = onp.context_embedding(P, G, li["token_embedding"], li["attention_mask"], st["patch_embeddings"][:, 0])
+    emb = li["token_embedding"].copy()
+    emb[li["attention_mask"] == 0] += 100.0
+    c1 = onp.context_embedding(P, G, emb, li["attention_mask"], st["patch_embeddings"][:, 0])
+    np.testing.assert_allclose(c0, c1, atol=1e-12)
+    emb2 = li["token_embedding"].copy()
+    emb2[:, 0] += 1.0                                        # a real token does matter
+    c2 = onp.context_embedding(P, G, emb2, li["attention_mask"], st["patch_embeddings"][:, 0])
+    assert np.abs(c2 - c0).max() > 1e-6
+
+
+def test_patch_tokens_do_not_see_the_action_token():
+    """base_vit.py:209-214: patch rows are independent of pos_embedding[256] / the action token."""
+    P, ins, st, im = _inputs(2)
+    bp, _ = onp.create_tasks(P, G, LEAVES, ins, st)
+    sink0, sink1 = {}, {}
+    tok = onp.dinov2(P, G, ENC, onp.normalize_images(im[:, 0]))[:, 1:]
+    onp.policy(bp, G, tok, sink0)
+    bp2 = {k: v.copy() for k, v in bp.items()}
+    bp2["encoder_pos_embedding"][:, :, -1] += 3.0
+    onp.policy(bp2, G, tok, sink1)
+    key = f"pol/Transformer_0/encoderblock_{G.layers - 1}/out"
+    np.testing.assert_allclose(sink0[key][:-1], sink1[key][:-1], atol=1e-12)
+    assert np.abs(sink0[key][-1] - sink1[key][-1]).max() > 1e-6
+
+
+def test_action_ranges_and_shape():
+    P, ins, st, im = _inputs()
+    bp, _ = onp.create_tasks(P, G, LEAVES, ins, st)
+    act, logit, _, _ = onp.sample_actions(P, G, ENC, bp, im)
+    assert act.shape == (3, G.horizon, G.action_dim)
+    assert np.abs(act[..., :6]).max() <= G.max_action                      # action_heads.py:469-470
+    assert set(np.unique(act[..., 6])) <= {0.0, 1.0}                        # :536
+    np.testing.assert_array_equal(act[..., 6], (logit >= 0).astype(float))
+
+
+def test_batched_equals_per_episode():
+    P, ins, st, im = _inputs()
+    bp, _ = onp.create_tasks(P, G, LEAVES, ins, st)
+    act, *_ = onp.sample_actions(P, G, ENC, bp, im)
+    b = 1
+    ins1 = {"language_instruction": {k: v[b:b + 1] for k, v in ins["language_instruction"].items()}}
+    bp1, _ = onp.create_tasks(P, G, LEAVES, ins1, {"patch_embeddings": st["patch_embeddings"][b:b + 1]})
+    act1, *_ = onp.sample_actions(P, G, ENC, bp1, im[b:b + 1])
+    np.testing.assert_allclose(act1[0], act[b], atol=1e-12)
+
+
+def test_ensemble_temp0_is_running_mean_of_aligned_predictions():
+    """action_ensemble.py:18-26."""
+    rng = np.random.default_rng(0)
+    H = 4
+    ens = onp.Ensembler(H, 0.0)
+    hist = []
+    for t in range(9):
+        a = rng.normal(size=(5, H, 7))
+        hist.append(a)
+        got = ens(a)
+        use = hist[-H:]
+        want = np.mean([p[:, len(use) - 1 - i] for i, p in enumerate(use)], axis=0)
+        np.testing.assert_allclose(got, want, atol=1e-12)
+
+
+def test_unnormalise_respects_mask():
+    """hypervla_interface.py:220-230."""
+    stats = syn.synthetic_dataset_statistics(G)["libero"]["action"]
+    a = np.random.default_rng(1).normal(size=(4, 7))
+    out = onp.unnormalize(a, stats)
+    np.testing.assert_allclose(out[:, :6], a[:, :6] * stats["std"][:6] + stats["mean"][:6])
+    np.testing.assert_array_equal(out[:, 6], a[:, 6])
