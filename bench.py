@@ -37,13 +37,25 @@ def algorithmic_flops(g):
     return dict(encoder=enc_linear + enc_attn + patch, policy=pol, fc1=2 * S * E * F)
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(g, params, seconds=12.0, batch=8):
     """The float32 torch-CPU restatement of the same step (oracle/hvla_ref_torch.py, "port"; JAX itself
     is not installable here), timed on this host's cores on a bounded sample."""
     from hypervla import synthetic as syn
     from hypervla.config import encoder_leaves, generated_leaves
     from oracle import hvla_ref_torch as ot
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     ref = ot.FullRef(params, g, generated_leaves(g), dict(encoder_leaves(g)), torch.float32)
     ins, st, im = syn.synthetic_instructions(batch, g), syn.synthetic_initial_state(batch, g), syn.synthetic_images(batch, g)
@@ -82,6 +94,7 @@ def main():
 
     from hypervla import synthetic as syn
     from hypervla.config import FULL
+    from hypervla.dp import max_over_ranks, whole_job_rate
     from hypervla.model import HyperVLA
     g, B = FULL, a.batch
     model = HyperVLA.from_synthetic(g, device=local, max_batch=B, enc_dtype=a.enc_dtype)
@@ -117,10 +130,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dom = ctx.profile_read()["fc1_gemm"]
     ctx.profile(0)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dev)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -159,7 +169,7 @@ def main():
     achieved = fl["fc1"] * B / (dom_ms * 1e-3) / 1e12
     ms_per_step = elapsed / a.steps * 1e3
     out = {
-        "metric": "actions_per_sec", "value": round(world * B * a.steps / elapsed, 2), "unit": "actions/s",
+        "metric": "actions_per_sec", "value": round(whole_job_rate(B, world, a.steps, elapsed), 2), "unit": "actions/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.enc_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: hypernet weight-gen once (untimed) + full sample_actions step "

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py (episode sharding, barrier, max-over-ranks)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist            # noqa: E402
+import torch.multiprocessing as mp          # noqa: E402
+
+from hypervla import synthetic as syn       # noqa: E402
+from hypervla.config import TINY            # noqa: E402
+from hypervla.dp import episode_range, max_over_ranks, whole_job_rate   # noqa: E402
+
+
+def test_episode_ranges_partition():
+    for total in (0, 1, 7, 8, 256, 8192):
+        for world in (1, 2, 3, 8):
+            r = [episode_range(total, world, k) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        episode_range(8, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = 3
+        ins = syn.synthetic_instructions(B, TINY, rank)          # per-rank synthetic shard (seed + rank)
+        digest = float(np.abs(ins["language_instruction"]["token_embedding"]).sum())
+        dist.barrier()
+        t = max_over_ranks(0.25 * (rank + 1))                     # slowest rank defines the job time
+        gathered = [None] * world
+        dist.all_gather_object(gathered, digest)
+        q.put((rank, t, gathered, whole_job_rate(B, world, 10, t)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=90) for _ in ps)
+    [p.join(30) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (r0, t0, g0, v0), (r1, t1, g1, v1) = out
+    assert t0 == t1 == 0.5                                       # max over ranks
+    assert g0 == g1 and g0[0] != g0[1]                           # different episodes on different ranks
+    assert v0 == v1 == 2 * 3 * 10 / 0.5
