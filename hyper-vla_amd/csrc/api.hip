@@ -520,6 +520,20 @@ int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches) {
   return HVLA_OK;
 }
 
+// diagnostics (not part of include/hvla.h): one encoder GEMM shape on the ctx's workspace
+int hvla_debug_gemm(hvla_ctx* ctx, int M, int N, int K, int epi, int variant, int iters, float* ms) {
+  if (!ctx || !ctx->loaded) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const void* A = K > ctx->g.E ? ctx->ws_g.p : ctx->ws_h.p;
+  void* out = epi == 3 ? ctx->ws_x.p : (epi == 1 ? ctx->ws_qkv.p : ctx->ws_g.p);
+  if (epi == 2 && K > ctx->g.E) return HVLA_E_SHAPE;
+  const EncLayerW& L = ctx->encw.layer[0];
+  const void* W = epi == 1 ? L.wqkv : (epi == 2 ? L.w1 : (K > ctx->g.E ? L.w2 : L.wo));
+  const float* bias = epi == 1 ? L.bqkv : (epi == 2 ? L.b1 : L.b2);
+  HIPCHK(ctx, debug_gemm(A, W, bias, L.ls1, out, M, N, K, epi, variant, iters, ms, nullptr));
+  return HVLA_OK;
+}
+
 int hvla_selftest(hvla_ctx* ctx, void* stream) {
   if (!ctx) return HVLA_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -85,8 +85,23 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   float u = k0 * (x + k1 * x * x * x);
   return 0.5f * x * (1.0f + tanhf(u));
 }
+// exact-erf GELU (HF ACT2FN["gelu"]).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32
+// round-off level) instead of libm erff: ~14 VALU ops with one v_rcp and one v_exp, which matters
+// because the fc1 epilogue applies it to B*257*3072 values per layer.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float r = fmaf(-p, e, 1.0f);
+  return copysignf(r, x);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+  return 0.5f * x * (1.0f + erf_fast(x * 0.7071067811865476f));
 }
 
 }  // namespace hvla

@@ -20,6 +20,10 @@
 //                      query on the lane) so softmax is in-lane and P feeds the PV MFMA from registers.
 //
 // Residual stream, LayerNorm statistics, softmax and GELU are f32; only MFMA operands are 16-bit.
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -77,6 +81,91 @@ struct GemmArgs {
   int qcols;             // QKV: columns < qcols are scaled by qscale
   float qscale;
 };
+
+// Epilogue shared by both GEMM kernels.  acc[nt][mt]: lane holds column m = m_base + 16 mt + fr and rows
+// n = n_base + 16 nt + 4 fq + {0..3}.  Loads of the residual tile are issued in batches ahead of the
+// stores (the compiler cannot prove the in-place x += ... stores do not alias the next loads and would
+// otherwise serialise 32 dependent round trips to HBM per lane).
+template <typename Op, int EPI, int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MT], const GemmArgs& g, int m_base, int n_base,
+                                              int fr, int fq) {
+  using T = typename Op::elem;
+  f32x4 b4[NT], l4[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    b4[nt] = *reinterpret_cast<const f32x4*>(g.bias + n_base + nt * 16 + fq * 4);
+    if constexpr (EPI == EPI_RES) l4[nt] = *reinterpret_cast<const f32x4*>(g.aux + n_base + nt * 16 + fq * 4);
+  }
+#pragma unroll
+  for (int mp = 0; mp < MT; mp += 2) {
+    f32x4 xin[2][NT];
+    bool ok[2];
+    size_t row[2];
+    int prow[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m_base + (mp + u) * 16 + fr;
+      ok[u] = m < g.M;
+      row[u] = (size_t)m;
+      prow[u] = 0;
+      if constexpr (EPI == EPI_PATCH) {
+        prow[u] = 1 + (m % g.P);
+        row[u] = (size_t)(m / g.P) * g.S + prow[u];
+      }
+      if constexpr (EPI == EPI_RES || EPI == EPI_PATCH) {
+        if (ok[u]) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int n = n_base + nt * 16 + fq * 4;
+            if constexpr (EPI == EPI_RES)
+              xin[u][nt] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.out) + row[u] * g.N + n);
+            else
+              xin[u][nt] = *reinterpret_cast<const f32x4*>(g.aux + (size_t)prow[u] * g.N + n);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + nt * 16 + fq * 4;
+        f32x4 v = acc[nt][mp + u];
+        if constexpr (EPI == EPI_PATCH) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= g.qscale;     // patch weights are stored x256 (16-bit range)
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b4[nt][r];
+        if constexpr (EPI == EPI_QKV) {
+          if (n < g.qcols) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= g.qscale;
+          }
+          typename Op::x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (T)v[r];
+          *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + row[u] * g.N + n) = o;
+        } else if constexpr (EPI == EPI_GELU) {
+          typename Op::x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (T)gelu_erf(v[r]);
+          *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + row[u] * g.N + n) = o;
+        } else if constexpr (EPI == EPI_RES) {
+          f32x4 x = xin[u][nt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = fmaf(v[r], l4[nt][r], x[r]);
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + row[u] * g.N + n) = x;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += xin[u][nt][r];
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + row[u] * g.N + n) = v;
+        }
+      }
+    }
+  }
+}
 
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = 72;   // GLD: padded LDS row (halves) = 144 B
 
@@ -162,52 +251,364 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: lane holds, per (nt, mt), column m = m0+64wm+16mt+fr and rows n = n0+64wn+16nt+4fq+{0..3}
+  gemm_epilogue<Op, EPI, 4, 4>(acc, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x256x64 block tile, 8 waves (2 along M x 4 along N, 128x64 each), operands staged global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction).  The LDS image is
+// lane-linear (hardware writes base + lane*16), so the bank swizzle chunk ^= (row & 7) is applied to the
+// per-lane SOURCE address and again on the ds_read_b128 address (guide §5.4 rule 21): 128-B rows then
+// read conflict-free.  Two LDS buffers (128 KiB): the DMA of K-tile t+1 is issued before the MFMAs of
+// tile t and drained (vmcnt(0)) at the single barrier per K-tile.
+constexpr int HBM_ = 256, HBN_ = 256;
+template <typename Op, int EPI, int ABL = 0>   // ABL (diagnostics only): 1 = no DMA in the loop, 2 = no MFMA
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
+  using T = typename Op::elem;
+  using X8 = typename Op::x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbm = (g.M + HBM_ - 1) / HBM_, nbn = g.N / HBN_;
+  int bid = blockIdx.x;
+  {
+    // blocks b and b+8 share an XCD (guide T1): give each XCD a contiguous run of logical tile ids ...
+    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  // ... and order the ids so that the ~32 tiles an XCD runs at once form a (8 M-tiles x GN N-tiles) patch:
+  // its A and W K-slices then stay in that XCD's 4 MiB L2 instead of being re-fetched from HBM/MALL.
+  const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
+  const int per_sc = nbm * GN;
+  const int sc = bid / per_sc, rem = bid % per_sc;
+  const int bm = rem / GN, bn = sc * GN + rem % GN;
+  const int m0 = bm * HBM_, n0 = bn * HBN_;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  // ---- LDS-DMA staging: instruction j of wave w fills rows [64 j + 8 w, +8), lane -> (row = lane >> 3,
+  // LDS chunk = lane & 7) and fetches global chunk (lane & 7) ^ (row & 7)
+  const int srow = wave * 8 + (lane >> 3);
+  const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
+  const T* asrc[4];
+  const T* wsrc[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + fr;
-    if (m >= g.M) continue;
+  for (int j = 0; j < 4; ++j) {
+    int m = m0 + 64 * j + srow;
+    m = m < g.M ? m : g.M - 1;
+    asrc[j] = A + (size_t)m * g.K + sch;
+    wsrc[j] = W + (size_t)(n0 + 64 * j + srow) * g.K + sch;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * 65536 + wave * 1024;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
-      f32x4 v = acc[nt][mt];
-      if constexpr (EPI == EPI_PATCH) {
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + 32768 + j * 8192), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][8];   // [n-tile][m-tile]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= g.qscale;     // patch weights are stored x256 (16-bit range)
-      }
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] += b4[r];
-      if constexpr (EPI == EPI_QKV) {
-        if (n < g.qcols) {
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw0 = ((fq) ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
+  const int a_off = (wm * 128 + fr) * 128, w_off = 32768 + (wn * 64 + fr) * 128;
+  const int KT = g.K / 64;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT && ABL != 1) stage(buf ^ 1, kt + 1);
+    const char* lb = smem + buf * 65536;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= g.qscale;
-        }
-        typename Op::x4 o;
+    for (int kk = 0; kk < 2; ++kk) {
+      const int sw = kk ? sw1 : sw0;
+      X8 fa[8], fw[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (T)v[r];
-        *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + (size_t)m * g.N + n) = o;
-      } else if constexpr (EPI == EPI_GELU) {
-        typename Op::x4 o;
+      for (int t = 0; t < 4; ++t) fw[t] = *reinterpret_cast<const X8*>(lb + w_off + t * 2048 + sw);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (T)gelu_erf(v[r]);
-        *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + (size_t)m * g.N + n) = o;
-      } else if constexpr (EPI == EPI_RES) {
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(g.aux + n);
-        f32x4* xp = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.N + n);
-        f32x4 x = *xp;
+      for (int t = 0; t < 8; ++t) fa[t] = *reinterpret_cast<const X8*>(lb + a_off + t * 2048 + sw);
+      if constexpr (ABL != 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = fmaf(v[r], ls[r], x[r]);
-        *xp = x;
-      } else {  // EPI_PATCH
-        const int b = m / g.P, p = m % g.P;
-        const f32x4 pe = *reinterpret_cast<const f32x4*>(g.aux + (size_t)(1 + p) * g.N + n);
+        for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += pe[r];
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + ((size_t)b * g.S + 1 + p) * g.N + n) = v;
+          for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = Op::mma16(fw[nt], fa[mt], acc[nt][mt]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(fw[t]));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(fa[t]));
       }
     }
+    __syncthreads();     // vmcnt(0) for the DMA of tile kt+1 + all waves done reading tile kt
   }
+  gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm256p_kernel: same tile / LDS image as gemm256_kernel, software-pipelined so that the matrix pipe
+// never waits on LDS or on the DMA issue:
+//   * two fragment register sets: F0 (k 0..31 of the K-tile) and F1 (k 32..63);
+//   * ONE barrier per K-tile, placed between the F0 and the F1 MFMAs.  At that point every wave holds
+//     F0(t), F1(t) in registers, so buffer t&1 is free: the LDS-DMA of tile t+2 is issued right there
+//     (a full K-tile ahead of its vmcnt(0) at the next barrier), interleaved with the F1(t) MFMAs;
+//   * F0(t+1) is read from the other buffer during the F1(t) MFMAs, F1(t+1) during the F0(t+1) MFMAs.
+template <typename Op, int EPI>
+__global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
+  using T = typename Op::elem;
+  using X8 = typename Op::x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbm = (g.M + HBM_ - 1) / HBM_, nbn = g.N / HBN_;
+  int bid = blockIdx.x;
+  {
+    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
+  const int per_sc = nbm * GN;
+  const int sc = bid / per_sc, rem = bid % per_sc;
+  const int bm = rem / GN, bn = sc * GN + rem % GN;
+  const int m0 = bm * HBM_, n0 = bn * HBN_;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const int srow = wave * 8 + (lane >> 3);
+  const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
+  uint32_t aoff[4], woff[4];          // element offsets (M*K < 2^31 is checked by the launcher)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int m = m0 + 64 * j + srow;
+    m = m < g.M ? m : g.M - 1;
+    aoff[j] = (uint32_t)m * (uint32_t)g.K + sch;
+    woff[j] = (uint32_t)(n0 + 64 * j + srow) * (uint32_t)g.K + sch;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * 65536 + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoff[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + woff[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + 32768 + j * 8192), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw0 = ((fq) ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
+  const int a_off = (wm * 128 + fr) * 128, w_off = 32768 + (wn * 64 + fr) * 128;
+  X8 a0[8], w0[4], a1[8], w1[4];
+  auto lds_frag = [&](X8 (&fa)[8], X8 (&fw)[4], int buf, int sw) {
+    const char* lb = smem + buf * 65536;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fw[t] = *reinterpret_cast<const X8*>(lb + w_off + t * 2048 + sw);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) fa[t] = *reinterpret_cast<const X8*>(lb + a_off + t * 2048 + sw);
+  };
+  auto mma_all = [&](const X8 (&fa)[8], const X8 (&fw)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = Op::mma16(fw[nt], fa[mt], acc[nt][mt]);
+  };
+  const int KT = g.K / 64;
+  stage(0, 0);
+  __syncthreads();
+  if (KT > 1) stage(1, 1);
+  lds_frag(a0, w0, 0, sw0);
+  lds_frag(a1, w1, 0, sw1);
+  // one K-tile; STAGE / READ are compile-time so the steady-state body is a single basic block the
+  // scheduler can interleave (MFMA : LDS-DMA : ds_read = 4 : 1 : 1.5)
+  auto ktile = [&](int kt, auto do_stage, auto do_read) {
+    const int buf = kt & 1;
+    mma_all(a0, w0);                        // F0(kt); the F1(kt) reads issued last iteration land meanwhile
+    __syncthreads();                        // vmcnt(0): tile kt+1 landed; lgkmcnt(0): buffer `buf` fully read
+    if constexpr (decltype(do_stage)::value) stage(buf, kt + 2);
+    if constexpr (decltype(do_read)::value) lds_frag(a0, w0, buf ^ 1, sw0);
+    mma_all(a1, w1);                        // F1(kt), interleaved with the DMA issue and the F0(kt+1) reads
+    if constexpr (decltype(do_stage)::value) {
+#define HVLA_SG(NDS)                                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); /* 4 MFMA            */ \
+  __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); /* 1 VMEM (LDS-DMA)  */ \
+  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); /* DS reads         */
+      HVLA_SG(2) HVLA_SG(2) HVLA_SG(2) HVLA_SG(2) HVLA_SG(1) HVLA_SG(1) HVLA_SG(1) HVLA_SG(1)
+#undef HVLA_SG
+    }
+    if constexpr (decltype(do_read)::value) lds_frag(a1, w1, buf ^ 1, sw1);
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  int kt = 0;
+  for (; kt + 2 < KT; ++kt) ktile(kt, Yes{}, Yes{});
+  if (kt + 1 < KT) ktile(kt++, No{}, Yes{});
+  ktile(kt, No{}, No{});
+  gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm256r_kernel — the production 256x256 GEMM.  Measured on the simpler kernel above: with one K-tile
+// in flight the LDS-DMA side alone needs 1.36 us per 64-deep K-tile (latency-bound) and the MFMA side
+// 1.33 us (every group of 8 MFMAs waits on its ds_reads), and the two overlap only half.  This version
+//   * stages K in 32-deep SLOTS (A 16 KB + W 16 KB) through a ring of 4 slots: three slots are landed or
+//     in flight ahead of the one being consumed (counted s_waitcnt vmcnt(8), raw s_barrier — a
+//     __syncthreads() would drain the DMA queue, guide §5 "Pipelining across barriers");
+//   * issues the DMA one piece per MFMA group (4 pieces per slot and wave), never as a burst;
+//   * rolls the fragment reads one MFMA group ahead (2 + 4 ping-pong register sets, 48 VGPRs) so the
+//     matrix pipe does not wait on LDS; the barrier of phase i sits BEFORE its last MFMA group, whose
+//     fragments are already in registers, so slot i is free for the DMA of slot i+4 right behind it and
+//     the first fragments of slot i+1 are fetched under that last group.
+// LDS rows are 64 B here; chunk' = chunk ^ LUT[(row >> 2) & 3], LUT = {0,2,3,1}, applied to the DMA source
+// address and to the read address, makes every ds_read_b128 lane group hit 16 distinct 16-B slots.
+template <typename Op, int EPI, int ABL = 0>   // ABL (diagnostics): 1 no DMA in loop, 2 no MFMA, 3 DMA only
+__global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs g) {
+  using T = typename Op::elem;
+  using X8 = typename Op::x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots x 32 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbm = (g.M + HBM_ - 1) / HBM_, nbn = g.N / HBN_;
+  int bid = blockIdx.x;
+  {
+    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
+  const int per_sc = nbm * GN;
+  const int sc = bid / per_sc, rem = bid % per_sc;
+  const int bm = rem / GN, bn = sc * GN + rem % GN;
+  const int m0 = bm * HBM_, n0 = bn * HBN_;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  // ---- DMA pieces: piece p in {A rows 16(8*0+w).., A rows 16(8+w).., W .., W ..}; lane -> row +(lane>>2),
+  // LDS chunk lane&3, source chunk (lane&3) ^ LUT[(lane>>4)&3]
+  const int lut = (0x1320 >> (((lane >> 4) & 3) * 4)) & 3;          // {0,2,3,1}
+  const int sch = ((lane & 3) ^ lut) * 8;
+  uint32_t poff[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int m = m0 + (j * 8 + wave) * 16 + (lane >> 2);
+    m = m < g.M ? m : g.M - 1;
+    poff[j] = (uint32_t)m * (uint32_t)g.K + sch;
+    poff[2 + j] = (uint32_t)(n0 + (j * 8 + wave) * 16 + (lane >> 2)) * (uint32_t)g.K + sch;
+  }
+  auto dma = [&](int piece, int slot_k /* phase index */) {
+    if (ABL == 1 && slot_k > 3) return;
+    char* dst = smem + (slot_k & 3) * 32768 + (piece >> 1) * 16384 + ((piece & 1) * 8 + wave) * 1024;
+    const T* src = (piece < 2 ? A : W) + poff[piece] + slot_k * 32;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rlut = (0x1320 >> (((fr >> 2) & 3) * 4)) & 3;
+  const int a_off = (wm * 128 + fr) * 64 + ((fq ^ rlut) << 4);
+  const int w_off = 16384 + (wn * 64 + fr) * 64 + ((fq ^ rlut) << 4);
+  auto rd_a = [&](X8 (&fa)[2], int slot_k, int mp) {
+    if (ABL == 3) return;
+    const char* lb = smem + (slot_k & 3) * 32768 + a_off + mp * 2048;
+    fa[0] = *reinterpret_cast<const X8*>(lb);
+    fa[1] = *reinterpret_cast<const X8*>(lb + 1024);
+  };
+  auto rd_w = [&](X8 (&fw)[4], int slot_k) {
+    if (ABL == 3) return;
+    const char* lb = smem + (slot_k & 3) * 32768 + w_off;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fw[t] = *reinterpret_cast<const X8*>(lb + t * 1024);
+  };
+  auto mma_g = [&](const X8 (&fa)[2], const X8 (&fw)[4], int mp) {
+    if constexpr (ABL == 2) {
+      asm volatile("" ::"v"(fa[0]), "v"(fa[1]), "v"(fw[0]), "v"(fw[1]), "v"(fw[2]), "v"(fw[3]));
+      return;
+    }
+    if constexpr (ABL == 3) return;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][2 * mp + u] = Op::mma16(fw[nt], fa[u], acc[nt][2 * mp + u]);
+  };
+  const int NP = g.K / 32;
+  X8 aA[2], aB[2], wA[4], wB[4];
+  // ---- prologue: slots 0,1,2 and the first piece of slot 3 in flight; slot 0 landed
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dma(p, s);
+  dma(0, 3);
+  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  rd_w(wA, 0);
+  rd_a(aA, 0, 0);
+  // One phase = one 32-deep slot = 4 MFMA groups of 8.  MODE 1: steady state (pieces 1..3 of slot i+3 at
+  // groups 0..2, piece 0 of slot i+4 at group 3); MODE 2: only finish slot i+3; MODE 0: no DMA.
+  // VM: outstanding DMA pieces allowed when slot i+1 must have landed.  LAST: no next slot to read.
+  auto phase = [&](int i, auto& wc, auto& wnx, auto mode, auto vm, auto last) {
+    constexpr int MODE = decltype(mode)::value, VM = decltype(vm)::value;
+    constexpr bool LAST = decltype(last)::value;
+    // program order == issue order we want; the sched_group_barrier chains pin it (the default schedule
+    // sinks each ds_read to just in front of its MFMAs and then waits for it: LDS latency fully exposed)
+#define HVLA_GRP(NDS, NVM)                                                         \
+  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); /* DS reads, next group */ \
+  if constexpr (NVM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);           \
+  __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); /* 8 MFMA, this group     */
+    rd_a(aB, i, 1);
+    if constexpr (MODE != 0) dma(1, i + 3);
+    mma_g(aA, wc, 0);
+    HVLA_GRP(2, MODE != 0)
+    rd_a(aA, i, 2);
+    if constexpr (MODE != 0) dma(2, i + 3);
+    mma_g(aB, wc, 1);
+    HVLA_GRP(2, MODE != 0)
+    rd_a(aB, i, 3);
+    if constexpr (MODE != 0) dma(3, i + 3);
+    mma_g(aA, wc, 2);
+    HVLA_GRP(2, MODE != 0)
+    if constexpr (!LAST) {
+      if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      rd_w(wnx, i + 1);
+      rd_a(aA, i + 1, 0);
+      if constexpr (MODE == 1) dma(0, i + 4);
+      mma_g(aB, wc, 3);
+      HVLA_GRP(6, MODE == 1)
+    } else {
+      mma_g(aB, wc, 3);
+    }
+#undef HVLA_GRP
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  int i = 0;
+  for (; i + 4 < NP; i += 2) {
+    phase(i, wA, wB, I1{}, I8{}, No{});
+    phase(i + 1, wB, wA, I1{}, I8{}, No{});
+  }
+  // tail: phases NP-4 .. NP-1
+  phase(i, wA, wB, I2{}, I8{}, No{});
+  phase(i + 1, wB, wA, I0{}, I4{}, No{});
+  phase(i + 2, wA, wB, I0{}, I0{}, No{});
+  phase(i + 3, wB, wA, I0{}, I0{}, Yes{});
+  gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,14 +791,29 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     SETA((gemm_kernel<Op, EPI_PATCH>)) SETA((gemm_kernel<Op, EPI_QKV>)) SETA((gemm_kernel<Op, EPI_GELU>))
     SETA((gemm_kernel<Op, EPI_RES>)) SETA((attention_kernel<Op>))
+    SETA((gemm256_kernel<Op, EPI_PATCH>)) SETA((gemm256_kernel<Op, EPI_QKV>)) SETA((gemm256_kernel<Op, EPI_GELU>))
+    SETA((gemm256_kernel<Op, EPI_RES>))
+    SETA((gemm256r_kernel<Op, EPI_PATCH>)) SETA((gemm256r_kernel<Op, EPI_QKV>)) SETA((gemm256r_kernel<Op, EPI_GELU>))
+    SETA((gemm256r_kernel<Op, EPI_RES>))
 #undef SETA
     attr = true;
   }
-  auto gemm = [&](auto kern, const void* A, const void* Wt, int Mm, int N, int K, const float* bias, const float* aux,
-                  void* out, int qcols) {
+  static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" force the older kernels
+  auto gemm = [&](auto kern, auto kern256, auto kern256r, const void* A, const void* Wt, int Mm, int N, int K,
+                  const float* bias, const float* aux, void* out, int qcols) {
     GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f : 1.f / 256.f};
-    const int nb = ((Mm + GBM - 1) / GBM) * (N / GBN);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), gsm, st, a);
+    const bool big = N % HBN_ == 0 && Mm >= 1024 && !(gsel && !strcmp(gsel, "128"));
+    const bool fits32 = (size_t)Mm * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
+    if (big && K >= 256 && fits32 && !(gsel && !strcmp(gsel, "simple"))) {
+      const int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
+      hipLaunchKernelGGL(kern256r, dim3(nb), dim3(512), 131072, st, a);
+    } else if (big) {
+      const int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
+      hipLaunchKernelGGL(kern256, dim3(nb), dim3(512), 131072, st, a);
+    } else {
+      const int nb = ((Mm + GBM - 1) / GBM) * (N / GBN);
+      hipLaunchKernelGGL(kern, dim3(nb), dim3(256), gsm, st, a);
+    }
   };
   // patch embedding
   pf.begin(0, st);
@@ -408,7 +824,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     hipLaunchKernelGGL(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
                        g.image_size, g.patch, g.grid(), Kp);
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * E + 255) / 256), dim3(256), 0, st, ws.x, w.pos, B, S, E);
-    gemm(gemm_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0);
+    gemm(gemm_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0);
   }
   pf.end(0, st);
   const int KT = (S + 31) / 32;
@@ -420,30 +836,94 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                        L.ln1_b, M, E, S);
     pf.end(1, st);
     pf.begin(2, st);
-    gemm(gemm_kernel<Op, EPI_QKV>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
+    gemm(gemm_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
     pf.end(2, st);
     pf.begin(3, st);
     hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3(KT * 64), asm_bytes, st,
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H);
     pf.end(3, st);
     pf.begin(4, st);
-    gemm(gemm_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0);
     pf.end(4, st);
     pf.begin(1, st);
     hipLaunchKernelGGL((layernorm_kernel<Op, false>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln2_s,
                        L.ln2_b, M, E, S);
     pf.end(1, st);
     pf.begin(5, st);
-    gemm(gemm_kernel<Op, EPI_GELU>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0);
+    gemm(gemm_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0);
     pf.end(5, st);
     pf.begin(6, st);
-    gemm(gemm_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0);
     pf.end(6, st);
   }
   pf.begin(1, st);
   hipLaunchKernelGGL((layernorm_kernel<Op, true>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s,
                      w.lnf_b, M, E, S);
   pf.end(1, st);
+  return hipGetLastError();
+}
+
+// diagnostics: time `iters` launches of one GEMM shape on workspace buffers (contents irrelevant)
+hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
+                      int K, int epi, int variant, int iters, float* ms, hipStream_t st) {
+  using Op = OpF16;
+  GemmArgs a{A, W, M, N, K, bias, aux, out, 256, 257, epi == EPI_QKV ? N / 3 : 0, 0.125f};
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  auto launch = [&]() {
+    const int nb256 = ((M + 255) / 256) * (N / 256), nb128 = ((M + 127) / 128) * (N / 128);
+    const size_t gsm = (size_t)2 * (GBM + GBN) * GLD * 2;
+#define L256(E, AB) hipLaunchKernelGGL((gemm256_kernel<Op, E, AB>), dim3(nb256), dim3(512), 131072, st, a)
+    if (variant == 0) {
+      if (epi == EPI_QKV) hipLaunchKernelGGL((gemm_kernel<Op, EPI_QKV>), dim3(nb128), dim3(256), gsm, st, a);
+      else if (epi == EPI_GELU) hipLaunchKernelGGL((gemm_kernel<Op, EPI_GELU>), dim3(nb128), dim3(256), gsm, st, a);
+      else hipLaunchKernelGGL((gemm_kernel<Op, EPI_RES>), dim3(nb128), dim3(256), gsm, st, a);
+    } else if (variant == 1) {
+      if (epi == EPI_QKV) L256(EPI_QKV, 0); else if (epi == EPI_GELU) L256(EPI_GELU, 0); else L256(EPI_RES, 0);
+    } else if (variant == 2) {
+      L256(EPI_QKV, 1);
+    } else if (variant == 3) {
+      L256(EPI_QKV, 2);
+    } else if (variant >= 6 && variant <= 8) {
+      if (variant == 6) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 1>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 7) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 2>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 8) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 3>), dim3(nb256), dim3(512), 131072, st, a);
+    } else if (variant == 5) {
+#define L256R(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E>), dim3(nb256), dim3(512), 131072, st, a)
+      if (epi == EPI_QKV) L256R(EPI_QKV); else if (epi == EPI_GELU) L256R(EPI_GELU); else L256R(EPI_RES);
+#undef L256R
+    } else if (variant == 4) {
+#define L256P(E) hipLaunchKernelGGL((gemm256p_kernel<Op, E>), dim3(nb256), dim3(512), 131072, st, a)
+      if (epi == EPI_QKV) L256P(EPI_QKV); else if (epi == EPI_GELU) L256P(EPI_GELU); else L256P(EPI_RES);
+#undef L256P
+    }
+#undef L256
+  };
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<Op, EPI_QKV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<Op, EPI_QKV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  launch();
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters; ++i) launch();
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  (void)hipEventElapsedTime(ms, e0, e1);
+  *ms /= iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return hipGetLastError();
 }
 

@@ -1,0 +1,23 @@
+"""Diagnostic (GPU box): time the encoder GEMM shapes / ablations through hvla_debug_gemm."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hyper-vla_amd")); sys.path.insert(0, ROOT)
+import torch
+from hypervla.config import FULL
+from hypervla.model import HyperVLA
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+m = HyperVLA.from_synthetic(FULL, max_batch=B)
+lib = m._ctx.lib
+lib.hvla_debug_gemm.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_float)]
+M = B * 257
+shapes = {"qkv": (M, 2304, 768, 1), "out": (M, 768, 768, 3), "fc1": (M, 3072, 768, 2), "fc2": (M, 768, 3072, 3)}
+names = {0: "128x128 regstage", 1: "256x256 lds-dma", 2: "256 no-DMA-in-loop", 3: "256 no-MFMA", 4: "256 pipelined", 5: "256 ring4", 6: "ring4 no-DMA", 7: "ring4 no-MFMA", 8: "ring4 DMA-only"}
+for nm, (M_, N, K, epi) in shapes.items():
+    for variant in (1, 5, 6, 7, 8):
+        if variant >= 6 and nm != "qkv" and nm != "fc2":
+            continue
+        ms = C.c_float()
+        e = 1 if variant >= 6 else epi
+        rc = lib.hvla_debug_gemm(m._ctx.h, M_, N, K, e, variant, 20, C.byref(ms))
+        tf = 2.0 * M_ * N * K / (ms.value * 1e-3) / 1e12
+        print(f"{nm:4s} M={M_} N={N} K={K} {names[variant]:20s} rc={rc} {ms.value*1e3:8.1f} us  {tf:7.1f} TF/s")
