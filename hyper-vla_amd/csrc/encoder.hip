@@ -80,6 +80,9 @@ struct GemmArgs {
   int P, S;              // PATCH row remap
   int qcols;             // QKV: columns < qcols are scaled by qscale
   float qscale;
+  int lda = 0, ldw = 0;  // row strides (elements) of A and W; 0 = K
+  int split_from = 0;    // RES only: logical tiles >= split_from are split along K into split_parts
+  int split_parts = 0;   // workgroups that accumulate into x with f32 atomics (tail-round fix)
 };
 
 // Epilogue shared by both GEMM kernels.  acc[nt][mt]: lane holds column m = m_base + 16 mt + fr and rows
@@ -163,6 +166,28 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MT], const 
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + row[u] * g.N + n) = v;
         }
       }
+    }
+  }
+}
+
+// split-K tail tiles of a RES GEMM: x += (acc + [part 0] bias) * layerscale with f32 atomics
+// (global_atomic_add_f32; order-dependent in the last bits, only the <= 1 % of rows of the tail tiles)
+template <int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue_atomic(const f32x4 (&acc)[NT][MT], const GemmArgs& g, int m_base,
+                                                     int n_base, int fr, int fq, bool add_bias) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n_base + nt * 16 + fq * 4;
+    f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(g.aux + n);
+    if (!add_bias) b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m_base + mt * 16 + fr;
+      if (m >= g.M) continue;
+      float* xp = reinterpret_cast<float*>(g.out) + (size_t)m * g.N + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) unsafeAtomicAdd(xp + r, (acc[nt][mt][r] + b4[r]) * l4[r]);
     }
   }
 }
@@ -350,111 +375,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm256p_kernel: same tile / LDS image as gemm256_kernel, software-pipelined so that the matrix pipe
-// never waits on LDS or on the DMA issue:
-//   * two fragment register sets: F0 (k 0..31 of the K-tile) and F1 (k 32..63);
-//   * ONE barrier per K-tile, placed between the F0 and the F1 MFMAs.  At that point every wave holds
-//     F0(t), F1(t) in registers, so buffer t&1 is free: the LDS-DMA of tile t+2 is issued right there
-//     (a full K-tile ahead of its vmcnt(0) at the next barrier), interleaved with the F1(t) MFMAs;
-//   * F0(t+1) is read from the other buffer during the F1(t) MFMAs, F1(t+1) during the F0(t+1) MFMAs.
-template <typename Op, int EPI>
-__global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
-  using T = typename Op::elem;
-  using X8 = typename Op::x8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nbm = (g.M + HBM_ - 1) / HBM_, nbn = g.N / HBN_;
-  int bid = blockIdx.x;
-  {
-    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
-  const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
-  const int per_sc = nbm * GN;
-  const int sc = bid / per_sc, rem = bid % per_sc;
-  const int bm = rem / GN, bn = sc * GN + rem % GN;
-  const int m0 = bm * HBM_, n0 = bn * HBN_;
-  const T* A = reinterpret_cast<const T*>(g.A);
-  const T* W = reinterpret_cast<const T*>(g.W);
-  const int srow = wave * 8 + (lane >> 3);
-  const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
-  uint32_t aoff[4], woff[4];          // element offsets (M*K < 2^31 is checked by the launcher)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + 64 * j + srow;
-    m = m < g.M ? m : g.M - 1;
-    aoff[j] = (uint32_t)m * (uint32_t)g.K + sch;
-    woff[j] = (uint32_t)(n0 + 64 * j + srow) * (uint32_t)g.K + sch;
-  }
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * 65536 + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoff[j] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + woff[j] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(base + 32768 + j * 8192), 16, 0, 0);
-    }
-  };
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fq = lane >> 4;
-  const int sw0 = ((fq) ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
-  const int a_off = (wm * 128 + fr) * 128, w_off = 32768 + (wn * 64 + fr) * 128;
-  X8 a0[8], w0[4], a1[8], w1[4];
-  auto lds_frag = [&](X8 (&fa)[8], X8 (&fw)[4], int buf, int sw) {
-    const char* lb = smem + buf * 65536;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) fw[t] = *reinterpret_cast<const X8*>(lb + w_off + t * 2048 + sw);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) fa[t] = *reinterpret_cast<const X8*>(lb + a_off + t * 2048 + sw);
-  };
-  auto mma_all = [&](const X8 (&fa)[8], const X8 (&fw)[4]) {
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = Op::mma16(fw[nt], fa[mt], acc[nt][mt]);
-  };
-  const int KT = g.K / 64;
-  stage(0, 0);
-  __syncthreads();
-  if (KT > 1) stage(1, 1);
-  lds_frag(a0, w0, 0, sw0);
-  lds_frag(a1, w1, 0, sw1);
-  // one K-tile; STAGE / READ are compile-time so the steady-state body is a single basic block the
-  // scheduler can interleave (MFMA : LDS-DMA : ds_read = 4 : 1 : 1.5)
-  auto ktile = [&](int kt, auto do_stage, auto do_read) {
-    const int buf = kt & 1;
-    mma_all(a0, w0);                        // F0(kt); the F1(kt) reads issued last iteration land meanwhile
-    __syncthreads();                        // vmcnt(0): tile kt+1 landed; lgkmcnt(0): buffer `buf` fully read
-    if constexpr (decltype(do_stage)::value) stage(buf, kt + 2);
-    if constexpr (decltype(do_read)::value) lds_frag(a0, w0, buf ^ 1, sw0);
-    mma_all(a1, w1);                        // F1(kt), interleaved with the DMA issue and the F0(kt+1) reads
-    if constexpr (decltype(do_stage)::value) {
-#define HVLA_SG(NDS)                                                          \
-  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); /* 4 MFMA            */ \
-  __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); /* 1 VMEM (LDS-DMA)  */ \
-  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); /* DS reads         */
-      HVLA_SG(2) HVLA_SG(2) HVLA_SG(2) HVLA_SG(2) HVLA_SG(1) HVLA_SG(1) HVLA_SG(1) HVLA_SG(1)
-#undef HVLA_SG
-    }
-    if constexpr (decltype(do_read)::value) lds_frag(a1, w1, buf ^ 1, sw1);
-  };
-  using Yes = std::integral_constant<bool, true>;
-  using No = std::integral_constant<bool, false>;
-  int kt = 0;
-  for (; kt + 2 < KT; ++kt) ktile(kt, Yes{}, Yes{});
-  if (kt + 1 < KT) ktile(kt++, No{}, Yes{});
-  ktile(kt, No{}, No{});
-  gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
-}
-
-// ------------------------------------------------------------------------------------------------
 // gemm256r_kernel — the production 256x256 GEMM.  Measured on the simpler kernel above: with one K-tile
 // in flight the LDS-DMA side alone needs 1.36 us per 64-deep K-tile (latency-bound) and the MFMA side
 // 1.33 us (every group of 8 MFMAs waits on its ds_reads), and the two overlap only half.  This version
@@ -468,8 +388,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 //     the first fragments of slot i+1 are fetched under that last group.
 // LDS rows are 64 B here; chunk' = chunk ^ LUT[(row >> 2) & 3], LUT = {0,2,3,1}, applied to the DMA source
 // address and to the read address, makes every ds_read_b128 lane group hit 16 distinct 16-B slots.
-template <typename Op, int EPI, int ABL = 0>   // ABL (diagnostics): 1 no DMA in loop, 2 no MFMA, 3 DMA only
-__global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs g) {
+template <typename Op, int EPI, int WM = 2, int ABL = 0>   // ABL (diagnostics): 1 no DMA in loop, 2 no MFMA, 3 DMA only
+__global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
+  // WM waves along M x 4 along N; per-wave tile (256 / WM) x 64 = MT x 4 MFMA tiles.
+  //   WM = 2:  8 waves, 128x64 per wave (128 accumulator VGPRs, 2 waves per SIMD)
+  //   WM = 4: 16 waves,  64x64 per wave ( 64 accumulator VGPRs, 4 waves per SIMD: more issue interleave)
+  constexpr int NWV = WM * 4, MT = 16 / WM, G = MT / 2, PPW = 32 / NWV;   // groups / DMA pieces per phase
+  static_assert(G == PPW, "one DMA piece per MFMA group");
   using T = typename Op::elem;
   using X8 = typename Op::x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots x 32 KB
@@ -477,10 +402,18 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nbm = (g.M + HBM_ - 1) / HBM_, nbn = g.N / HBN_;
-  int bid = blockIdx.x;
+  int bid = blockIdx.x, part = 0, nparts = 1;
   {
-    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    const int nfull = g.split_parts > 1 ? g.split_from : nbm * nbn;
+    if (bid < nfull) {
+      const int q = nfull / 8, r = nfull % 8, xcd = bid % 8;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    } else {                      // tail tile, split along K
+      const int e = bid - nfull;
+      nparts = g.split_parts;
+      part = e % nparts;
+      bid = nfull + e / nparts;
+    }
   }
   const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
   const int per_sc = nbm * GN;
@@ -489,33 +422,40 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs g) {
   const int m0 = bm * HBM_, n0 = bn * HBN_;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
-  // ---- DMA pieces: piece p in {A rows 16(8*0+w).., A rows 16(8+w).., W .., W ..}; lane -> row +(lane>>2),
-  // LDS chunk lane&3, source chunk (lane&3) ^ LUT[(lane>>4)&3]
-  const int lut = (0x1320 >> (((lane >> 4) & 3) * 4)) & 3;          // {0,2,3,1}
+  // ---- DMA pieces: a slot has 32 pieces of 1 KiB (0..15: A rows 16 q.., 16..31: W rows); wave w moves
+  // pieces q = w + NWV * j.  lane -> row + (lane >> 2), LDS chunk lane & 3, source chunk (lane & 3) ^ LUT
+  const int lut = (0x1320 >> (((lane >> 4) & 3) * 4)) & 3;          // {0,2,3,1}[(row >> 2) & 3]
   const int sch = ((lane & 3) ^ lut) * 8;
-  uint32_t poff[4];
+  const int NP = g.K / 32 / nparts;            // phases of this workgroup: [part * NP, (part + 1) * NP)
+  uint32_t poff[PPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int m = m0 + (j * 8 + wave) * 16 + (lane >> 2);
-    m = m < g.M ? m : g.M - 1;
-    poff[j] = (uint32_t)m * (uint32_t)g.K + sch;
-    poff[2 + j] = (uint32_t)(n0 + (j * 8 + wave) * 16 + (lane >> 2)) * (uint32_t)g.K + sch;
+  for (int j = 0; j < PPW; ++j) {
+    const int q = wave + NWV * j;
+    if (q < 16) {
+      int m = m0 + q * 16 + (lane >> 2);
+      m = m < g.M ? m : g.M - 1;
+      poff[j] = (uint32_t)m * (uint32_t)(g.lda ? g.lda : g.K) + sch;
+    } else {
+      poff[j] = (uint32_t)(n0 + (q - 16) * 16 + (lane >> 2)) * (uint32_t)(g.ldw ? g.ldw : g.K) + sch;
+    }
+    poff[j] += (uint32_t)(part * NP * 32);
   }
-  auto dma = [&](int piece, int slot_k /* phase index */) {
+  auto dma = [&](int j, int slot_k /* phase index */) {
     if (ABL == 1 && slot_k > 3) return;
-    char* dst = smem + (slot_k & 3) * 32768 + (piece >> 1) * 16384 + ((piece & 1) * 8 + wave) * 1024;
-    const T* src = (piece < 2 ? A : W) + poff[piece] + slot_k * 32;
+    const int q = wave + NWV * j;                        // wave-uniform
+    char* dst = smem + (slot_k & 3) * 32768 + q * 1024;
+    const T* src = (q < 16 ? A : W) + poff[j] + slot_k * 32;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
-  f32x4 acc[4][8];
+  f32x4 acc[4][MT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
   const int rlut = (0x1320 >> (((fr >> 2) & 3) * 4)) & 3;
-  const int a_off = (wm * 128 + fr) * 64 + ((fq ^ rlut) << 4);
+  const int a_off = (wm * (16 * MT) + fr) * 64 + ((fq ^ rlut) << 4);
   const int w_off = 16384 + (wn * 64 + fr) * 64 + ((fq ^ rlut) << 4);
   auto rd_a = [&](X8 (&fa)[2], int slot_k, int mp) {
     if (ABL == 3) return;
@@ -540,21 +480,21 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs g) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[nt][2 * mp + u] = Op::mma16(fw[nt], fa[u], acc[nt][2 * mp + u]);
   };
-  const int NP = g.K / 32;
   X8 aA[2], aB[2], wA[4], wB[4];
   // ---- prologue: slots 0,1,2 and the first piece of slot 3 in flight; slot 0 landed
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) dma(p, s);
+    for (int j = 0; j < PPW; ++j) dma(j, sl);
   dma(0, 3);
-  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
   rd_w(wA, 0);
   rd_a(aA, 0, 0);
-  // One phase = one 32-deep slot = 4 MFMA groups of 8.  MODE 1: steady state (pieces 1..3 of slot i+3 at
-  // groups 0..2, piece 0 of slot i+4 at group 3); MODE 2: only finish slot i+3; MODE 0: no DMA.
-  // VM: outstanding DMA pieces allowed when slot i+1 must have landed.  LAST: no next slot to read.
+  // One phase = one 32-deep slot = G MFMA groups of 8.  MODE 1: steady state (pieces 1.. of slot i+3 at the
+  // first groups, piece 0 of slot i+4 behind the barrier); MODE 2: only finish slot i+3; MODE 0: no DMA.
+  // VM: slots that may still be in flight when slot i+1 must have landed.  LAST: no next slot to read.
   auto phase = [&](int i, auto& wc, auto& wnx, auto mode, auto vm, auto last) {
     constexpr int MODE = decltype(mode)::value, VM = decltype(vm)::value;
     constexpr bool LAST = decltype(last)::value;
@@ -568,47 +508,54 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs g) {
     if constexpr (MODE != 0) dma(1, i + 3);
     mma_g(aA, wc, 0);
     HVLA_GRP(2, MODE != 0)
-    rd_a(aA, i, 2);
-    if constexpr (MODE != 0) dma(2, i + 3);
-    mma_g(aB, wc, 1);
-    HVLA_GRP(2, MODE != 0)
-    rd_a(aB, i, 3);
-    if constexpr (MODE != 0) dma(3, i + 3);
-    mma_g(aA, wc, 2);
-    HVLA_GRP(2, MODE != 0)
+    if constexpr (G == 4) {
+      rd_a(aA, i, 2);
+      if constexpr (MODE != 0) dma(2, i + 3);
+      mma_g(aB, wc, 1);
+      HVLA_GRP(2, MODE != 0)
+      rd_a(aB, i, 3);
+      if constexpr (MODE != 0) dma(3, i + 3);
+      mma_g(aA, wc, 2);
+      HVLA_GRP(2, MODE != 0)
+    }
     if constexpr (!LAST) {
-      if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if constexpr (VM * PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (VM * PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (VM * PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       rd_w(wnx, i + 1);
       rd_a(aA, i + 1, 0);
       if constexpr (MODE == 1) dma(0, i + 4);
-      mma_g(aB, wc, 3);
+      mma_g(aB, wc, G - 1);
       HVLA_GRP(6, MODE == 1)
     } else {
-      mma_g(aB, wc, 3);
+      mma_g(aB, wc, G - 1);
     }
 #undef HVLA_GRP
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-  using I4 = std::integral_constant<int, 4>;
-  using I8 = std::integral_constant<int, 8>;
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
   int i = 0;
   for (; i + 4 < NP; i += 2) {
-    phase(i, wA, wB, I1{}, I8{}, No{});
-    phase(i + 1, wB, wA, I1{}, I8{}, No{});
+    phase(i, wA, wB, I1{}, I2{}, No{});
+    phase(i + 1, wB, wA, I1{}, I2{}, No{});
   }
   // tail: phases NP-4 .. NP-1
-  phase(i, wA, wB, I2{}, I8{}, No{});
-  phase(i + 1, wB, wA, I0{}, I4{}, No{});
+  phase(i, wA, wB, I2{}, I2{}, No{});
+  phase(i + 1, wB, wA, I0{}, I1{}, No{});
   phase(i + 2, wA, wB, I0{}, I0{}, No{});
   phase(i + 3, wB, wA, I0{}, I0{}, Yes{});
-  gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+  if constexpr (EPI == EPI_RES) {
+    if (nparts > 1) {
+      gemm_epilogue_atomic<4, MT>(acc, g, m0 + wm * (16 * MT), n0 + wn * 64, fr, fq, part == 0);
+      return;
+    }
+  }
+  gemm_epilogue<Op, EPI, 4, MT>(acc, g, m0 + wm * (16 * MT), n0 + wn * 64, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -799,13 +746,34 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     attr = true;
   }
   static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" force the older kernels
+  static const bool nosplit = getenv("HVLA_NOSPLIT") != nullptr;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
   auto gemm = [&](auto kern, auto kern256, auto kern256r, const void* A, const void* Wt, int Mm, int N, int K,
-                  const float* bias, const float* aux, void* out, int qcols) {
+                  const float* bias, const float* aux, void* out, int qcols, bool is_res = false) {
     GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f : 1.f / 256.f};
     const bool big = N % HBN_ == 0 && Mm >= 1024 && !(gsel && !strcmp(gsel, "128"));
     const bool fits32 = (size_t)Mm * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
     if (big && K >= 256 && fits32 && !(gsel && !strcmp(gsel, "simple"))) {
-      const int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
+      int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
+      // tail-round fix (in-place residual epilogue only): when a few tiles spill into an extra round on the
+      // 256 CUs, split those along K over otherwise idle CUs
+      const int remt = nb % ncu;
+      if (is_res && nb > ncu && remt > 0 && remt <= ncu / 8 && !nosplit) {
+        const int NPt = K / 32;
+        int parts = 1;
+        for (int c = NPt / 4; c >= 2; --c)
+          if (NPt % c == 0 && (NPt / c) % 2 == 0 && remt * c <= ncu) { parts = c; break; }
+        if (parts > 1) {
+          a.split_from = nb - remt;
+          a.split_parts = parts;
+          nb = a.split_from + remt * parts;
+        }
+      }
       hipLaunchKernelGGL(kern256r, dim3(nb), dim3(512), 131072, st, a);
     } else if (big) {
       const int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
@@ -843,7 +811,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H);
     pf.end(3, st);
     pf.begin(4, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
     pf.end(4, st);
     pf.begin(1, st);
     hipLaunchKernelGGL((layernorm_kernel<Op, false>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln2_s,
@@ -853,7 +821,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     gemm(gemm_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0);
     pf.end(5, st);
     pf.begin(6, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
     pf.end(6, st);
   }
   pf.begin(1, st);
@@ -868,6 +836,8 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st) {
   using Op = OpF16;
   GemmArgs a{A, W, M, N, K, bias, aux, out, 256, 257, epi == EPI_QKV ? N / 3 : 0, 0.125f};
+  if (const char* e = getenv("HVLA_DBG_LDA")) a.lda = K + atoi(e);
+  if (const char* e = getenv("HVLA_DBG_LDW")) a.ldw = K + atoi(e);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
@@ -886,17 +856,17 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
     } else if (variant == 3) {
       L256(EPI_QKV, 2);
     } else if (variant >= 6 && variant <= 8) {
-      if (variant == 6) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 1>), dim3(nb256), dim3(512), 131072, st, a);
-      if (variant == 7) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 2>), dim3(nb256), dim3(512), 131072, st, a);
-      if (variant == 8) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 3>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 6) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 2, 1>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 7) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 2, 2>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 8) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 2, 3>), dim3(nb256), dim3(512), 131072, st, a);
     } else if (variant == 5) {
 #define L256R(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E>), dim3(nb256), dim3(512), 131072, st, a)
       if (epi == EPI_QKV) L256R(EPI_QKV); else if (epi == EPI_GELU) L256R(EPI_GELU); else L256R(EPI_RES);
 #undef L256R
     } else if (variant == 4) {
-#define L256P(E) hipLaunchKernelGGL((gemm256p_kernel<Op, E>), dim3(nb256), dim3(512), 131072, st, a)
-      if (epi == EPI_QKV) L256P(EPI_QKV); else if (epi == EPI_GELU) L256P(EPI_GELU); else L256P(EPI_RES);
-#undef L256P
+#define L256R4(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E, 4>), dim3(nb256), dim3(1024), 131072, st, a)
+      if (epi == EPI_QKV) L256R4(EPI_QKV); else if (epi == EPI_GELU) L256R4(EPI_GELU); else L256R4(EPI_RES);
+#undef L256R4
     }
 #undef L256
   };
@@ -905,14 +875,14 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<Op, EPI_QKV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<Op, EPI_QKV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   launch();
