@@ -16,7 +16,7 @@
 //   layernorm_kernel   f32 rows -> 16-bit rows (eps 1e-6), one wavefront per row; final variant drops the
 //                      CLS row and writes the f32 patch tokens the policy consumes
 //   attention_kernel   S = 257, head_dim 64: one workgroup per (image, head), one wavefront per 32-query
-//                      block; K and V^T resident in LDS; transposed scores (keys on accumulator rows,
+//                      block; K and V resident in LDS (V consumed through ds_read_b64_tr_b16); transposed scores (keys on accumulator rows,
 //                      query on the lane) so softmax is in-lane and P feeds the PV MFMA from registers.
 //
 // Residual stream, LayerNorm statistics, softmax and GELU are f32; only MFMA operands are 16-bit.
@@ -619,23 +619,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention, head_dim 64.  qkv [B*S][3E] 16-bit (q already scaled by 1/sqrt(64)); out o [B*S][E].
+// Attention, head_dim 64.  qkv [B*S][3E] 16-bit (q already scaled by log2(e)/sqrt(64)); out o [B*S][E].
 constexpr int AKLD = 72;          // K row stride in LDS (halves): 144 B
+constexpr int AVLD = 64;          // V row stride (halves): 128 B, 64-B halves swapped on rows with bit 1 set
+
+// transposed LDS read (ds_read_b64_tr_b16, guide T10): per 16-lane group a 4-row x 16-column block of 16-bit
+// elements comes back column-major; lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane i
+// receives column i of the 4 rows.  EXEC must be all ones.
+typedef short hvla_s4 __attribute__((__vector_size__(4 * sizeof(short))));
+template <typename X8>
+__device__ __forceinline__ X8 tr_read2(const void* p0, const void* p1) {
+  const hvla_s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hvla_s4*)p0);
+  const hvla_s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hvla_s4*)p1);
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(X8, v);
+}
+
 template <typename Op>
 __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, typename Op::elem* __restrict__ o,
                                  int S, int E, int H) {
+  // S = 32 * NW + 1 tokens.  NW waves of 64 lanes: wave w owns queries [32 w, 32 w + 32) on the matrix cores;
+  // the one remaining query (the last token) is done co-operatively on the VALU, wave w taking key tile w,
+  // and combined through LDS.  8 waves per workgroup at S = 257 (2 per SIMD) so that two workgroups share a
+  // CU (the 9-wave version only ever had one resident).
   using T = typename Op::elem;
   using X8 = typename Op::x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int KT = (S + 31) / 32, SP = KT * 32;
-  const int VLD = SP + 8;                                 // V^T row stride (halves)
-  T* Ks = reinterpret_cast<T*>(smem);                      // [SP][AKLD]
-  T* Vt = Ks + SP * AKLD;                                  // [64][VLD]
+  const int NW = (S - 1) / 32, KT = NW + 1, SP = KT * 32;
+  T* Ks = reinterpret_cast<T*>(smem);                      // [SP][64]  keys, 16-B chunks XOR-swizzled by key & 7
+  T* Vs = Ks + SP * AVLD;                                  // [SP][64]  values, row-major (read transposed)
+  float* part = reinterpret_cast<float*>(Vs + SP * AVLD);  // [KT][66]   partial (max, sum, O[64]) of the last query
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthr = blockDim.x;
   const size_t rowstride = (size_t)3 * E;
   const T* base = qkv + (size_t)b * S * rowstride + head * 64;
-  // ---- stage K (row-major) and V^T (keys permuted: bits 2 and 3 of key&31 swapped)
+  // ---- stage K and V: 16 B per thread and chunk (zero rows for the padding keys)
   for (int i = tid; i < SP * 8; i += nthr) {
     const int key = i >> 3, ch = i & 7;
     X8 kv, vv;
@@ -646,67 +665,81 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 #pragma unroll
       for (int j = 0; j < 8; ++j) kv[j] = (T)0.f, vv[j] = (T)0.f;
     }
-    *reinterpret_cast<X8*>(Ks + key * AKLD + ch * 8) = kv;
-    const int kl = key & 31;
-    const int vpos = (key & ~31) | (kl & 0x13) | ((kl & 4) << 1) | ((kl & 8) >> 1);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VLD + vpos] = vv[j];
+    *reinterpret_cast<X8*>(Ks + key * AVLD + ((ch ^ (key & 7)) * 8)) = kv;
+    *reinterpret_cast<X8*>(Vs + key * AVLD + ((ch ^ (((key >> 1) & 1) << 2)) * 8)) = vv;
   }
   // ---- this wave's 32 queries as B fragments (natural d order): 4 k-steps of 16
   const int col = lane & 31, half = lane >> 5;
-  int q = wave * 32 + col;
-  const bool qvalid = q < S;
-  q = qvalid ? q : S - 1;
+  const int q = wave * 32 + col;                           // always < S - 1
   X8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const X8*>(base + (size_t)q * rowstride + ks * 16 + half * 8);
+  // the extra query (token S-1): lane holds d = 32 * half .. +32 of it
+  X8 qx[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) qx[c] = *reinterpret_cast<const X8*>(base + (size_t)(S - 1) * rowstride + half * 32 + c * 8);
   __syncthreads();
 
-  const float LOG2E = 1.4426950408889634f;
-  float m2 = -1e30f, lsum = 0.f;     // running max (log2 domain), this half's partial denominator
+  // per-lane part of the transposed-read address: row (half * 4 + q), column 16 * dgrp + 4 p, and the 64-B
+  // half swap of rows with bit 1 set (q >= 2)
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int vsw = ((i16 >> 3) & 1) << 5;
+  const T* vtr = Vs + ((g16 >> 1) * 4 + (i16 >> 2)) * AVLD + (g16 & 1) * 16 + (i16 & 3) * 4;
+  const int kswz = col & 7;                                // K chunk swizzle of this lane's key row
+  // Two passes over the resident K tiles instead of an online softmax: the matrix pipe is idle most of the
+  // time here (head_dim 64: 8 MFMAs per 1024 scores), so recomputing K.Q^T (4 MFMAs) is cheaper than the
+  // per-tile rescale of O and the running-max bookkeeping.
+  //   pass 1: row max (scores are in the log2 domain: q carries 1/sqrt(64) * log2 e from the QKV epilogue)
+  //   pass 2: accumulator initialised to -max, so p = exp2(acc) with no subtract; invalid keys get -1e30
+  f32x16 init;                      // 0 for real keys, -1e30 for the padding keys of the last tile
+#pragma unroll
+  for (int r = 0; r < 16; ++r) init[r] = ((KT - 1) * 32 + crow(r, half) < S) ? 0.f : -1e30f;
+  auto kfrag = [&](int kt, int ks) {
+    return *reinterpret_cast<const X8*>(Ks + (kt * 32 + col) * AVLD + (((2 * ks + half) ^ kswz) * 8));
+  };
+  float mx = -1e30f;
+  for (int kt = 0; kt < KT; ++kt) {
+    f32x16 s;
+    if (kt == KT - 1) s = init;
+    else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s = Op::mma32(kfrag(kt, ks), qf[ks], s);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float lsum = 0.f;                 // this half's partial denominator
   f32x16 O[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) O[0][r] = 0.f, O[1][r] = 0.f;
   for (int kt = 0; kt < KT; ++kt) {
     f32x16 s;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    const T* kp = Ks + (kt * 32 + col) * AKLD + half * 8;
+    for (int r = 0; r < 16; ++r) s[r] = (kt == KT - 1 ? init[r] : 0.f) - mx;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) s = Op::mma32(*reinterpret_cast<const X8*>(kp + ks * 16), qf[ks], s);
-    float tmax = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = s[r] * LOG2E;
-      if (kt == KT - 1 && kt * 32 + crow(r, half) >= S) v = -1e30f;
-      s[r] = v;
-      tmax = fmaxf(tmax, v);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mn = fmaxf(m2, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
-    m2 = mn;
-    float psum = 0.f;
+    for (int ks = 0; ks < 4; ++ks) s = Op::mma32(kfrag(kt, ks), qf[ks], s);
     X8 pf[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[r] - mn);
-      psum += p;
+      const float p = __builtin_amdgcn_exp2f(s[r]);
+      lsum += p;
       pf[r >> 3][r & 7] = (T)p;
     }
-    lsum = lsum * alpha + psum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) O[0][r] *= alpha, O[1][r] *= alpha;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const T* vp = Vt + (mt * 32 + col) * VLD + kt * 32 + half * 8;
 #pragma unroll
-      for (int sstep = 0; sstep < 2; ++sstep)
-        O[mt] = Op::mma32(*reinterpret_cast<const X8*>(vp + sstep * 16), pf[sstep], O[mt]);
+      for (int sstep = 0; sstep < 2; ++sstep) {
+        // A operand = V^T: lane (d = 32 mt + (l & 31), half) needs keys 16 s + 8 (j >> 2) + 4 half + (j & 3)
+        const T* v0 = vtr + ((kt * 32 + sstep * 16) * AVLD) + ((mt * 32) ^ vsw);
+        O[mt] = Op::mma32(tr_read2<X8>(v0, v0 + 8 * AVLD), pf[sstep], O[mt]);
+      }
     }
   }
   const float inv = 1.f / (lsum + __shfl_xor(lsum, 32, 64));
-  if (qvalid) {
+  {
     T* op = o + ((size_t)b * S + q) * E + head * 64;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -717,6 +750,56 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         for (int r = 0; r < 4; ++r) v4[r] = (T)(O[mt][g4 * 4 + r] * inv);
         *reinterpret_cast<typename Op::x4*>(op + mt * 32 + g4 * 8 + half * 4) = v4;
       }
+  }
+  // ---- the last query, VALU: wave w scores key tile w (lane = key, the two halves split d), wave 0 also the
+  // final key S-1; partial softmax + partial P.V (lane = d); combine across waves through LDS.
+  {
+    auto score = [&](int key) {          // sum over this half's 32 d
+      float a = 0.f;
+      const T* kr = Ks + key * AVLD;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const X8 kv = *reinterpret_cast<const X8*>(kr + (((half * 4 + c) ^ (key & 7)) * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a = fmaf((float)qx[c][j], (float)kv[j], a);
+      }
+      return a + __shfl_xor(a, 32, 64);
+    };
+    const int nk = wave == 0 ? 2 : 1;    // wave 0: tile 0 and the single key of tile KT-1
+    for (int t = 0; t < nk; ++t) {
+      const int tile = t == 0 ? wave : KT - 1;
+      const int key = tile * 32 + col;
+      const bool valid = key < S;
+      const float sc = valid ? score(valid ? key : 0) : -1e30f;
+      float m = sc;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      const float p = valid ? __builtin_amdgcn_exp2f(sc - m) : 0.f;
+      float l = p;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) l += __shfl_xor(l, off, 64);
+      float od = 0.f;                    // lane = d
+      for (int i = 0; i < 32; ++i) {
+        const float pi = __shfl(p, i, 64);
+        const int k2 = tile * 32 + i;
+        od = fmaf(pi, (float)Vs[k2 * AVLD + (lane ^ (((k2 >> 1) & 1) << 5))], od);
+      }
+      float* pp = part + tile * 66;
+      if (lane == 0) pp[0] = m, pp[1] = l;
+      pp[2 + lane] = od;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float M = -1e30f;
+    for (int t = 0; t < KT; ++t) M = fmaxf(M, part[t * 66]);
+    float L = 0.f, od = 0.f;
+    for (int t = 0; t < KT; ++t) {
+      const float f = __builtin_amdgcn_exp2f(part[t * 66] - M);
+      L = fmaf(part[t * 66 + 1], f, L);
+      od = fmaf(part[t * 66 + 2 + lane], f, od);
+    }
+    o[((size_t)b * S + (S - 1)) * E + head * 64 + lane] = (T)(od / L);
   }
 }
 
@@ -755,7 +838,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   }
   auto gemm = [&](auto kern, auto kern256, auto kern256r, const void* A, const void* Wt, int Mm, int N, int K,
                   const float* bias, const float* aux, void* out, int qcols, bool is_res = false) {
-    GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f : 1.f / 256.f};
+    GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
     const bool big = N % HBN_ == 0 && Mm >= 1024 && !(gsel && !strcmp(gsel, "128"));
     const bool fits32 = (size_t)Mm * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
     if (big && K >= 256 && fits32 && !(gsel && !strcmp(gsel, "simple"))) {
@@ -795,8 +878,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     gemm(gemm_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0);
   }
   pf.end(0, st);
-  const int KT = (S + 31) / 32;
-  const size_t asm_bytes = ((size_t)KT * 32 * AKLD + (size_t)64 * (KT * 32 + 8)) * sizeof(T);
+  const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
+  const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * 66 * sizeof(float);
   for (int l = 0; l < g.enc_layers; ++l) {
     const EncLayerW& L = w.layer[l];
     pf.begin(1, st);
@@ -807,7 +890,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     gemm(gemm_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
     pf.end(2, st);
     pf.begin(3, st);
-    hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3(KT * 64), asm_bytes, st,
+    hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H);
     pf.end(3, st);
     pf.begin(4, st);
