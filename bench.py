@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="episodes per GPU")
     ap.add_argument("--enc-dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (BASELINE config 3)")
     a = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -88,7 +89,8 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torch.distributed.run even at N = 1
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # RCCL; used only for barrier + max(time)
 
@@ -104,7 +106,7 @@ def main():
     ctx = model._ctx
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -121,18 +123,38 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    ctx.profile(1)                     # HIP events around the dominant kernel only, on the launch stream
+    eager_step = step
+    if a.graph:                        # capture one step (launches only, no allocation / sync inside hvla_step)
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):
+            stream = model._stream()
+            step()                     # warm the side stream
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                stream = model._stream()
+                step()
+        stream = model._stream()
+        step = graph.replay
+        step()
+    ctx.profile(0 if a.graph else 1)   # HIP events around the dominant kernel only, on the launch stream
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    if a.graph:                        # events cannot be recorded inside a replayed graph: time the dominant
+        ctx.profile(1)                 # kernel on eager launches of the same step right after the timed region
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize(dev)
     dom = ctx.profile_read()["fc1_gemm"]
     ctx.profile(0)
     elapsed = max_over_ranks(elapsed, dev)
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -146,7 +168,7 @@ def main():
         lat.append((time.perf_counter() - t1) * 1e3)
     ctx.profile(2)
     for _ in range(3):
-        step()
+        eager_step()
     torch.cuda.synchronize(dev)
     br = ctx.profile_read()
     ctx.profile(0)
@@ -164,6 +186,18 @@ def main():
     torch.cuda.synchronize(dev)
     pol_ms = (time.perf_counter() - t1) * 1e3 / 20
 
+    traffic = None                      # HBM bytes per launch of the dominant kernel: 2 * FETCH_SIZE + WRITE_SIZE
+    try:                                # (gfx950 FETCH_SIZE counts half of a wide streaming read), from the
+        import csv                      # committed rocprofv3 --pmc passes of this same command (profiles/)
+        vals = {}
+        for nm in ("fetch", "write"):
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_pmc_{nm}_size_by_kernel.csv"))):
+                if "gemm256r_kernel<hvla::OpF16, 2" in row["kernel"]:
+                    vals[nm] = float(row["mean"]) * 1024.0
+        if B == 256 and a.enc_dtype == "f16" and len(vals) == 2:
+            traffic = int(2 * vals["fetch"] + vals["write"])
+    except Exception:
+        traffic = None
     fl = algorithmic_flops(g)
     dom_ms = dom[0] / max(dom[1], 1)
     achieved = fl["fc1"] * B / (dom_ms * 1e-3) / 1e12
@@ -177,11 +211,13 @@ def main():
                                "[4,7] action chunk); 1 action = 1 sample-step",
                    "batch_per_gpu": B, "global_batch": world * B, "encoder": "DINOv2-base (reference parity, E=768)",
                    "parallelism": f"episode-dp{world} (no collectives)",
-                   "encoder_operands": a.enc_dtype, "policy_operands": "split-bf16 (bf16x3)"},
+                   "encoder_operands": a.enc_dtype, "policy_operands": "split-bf16 (bf16x3)",
+                   "launch": "hipGraph replay" if a.graph else "eager (about 95 launches per step)"},
         "p50_step_latency_ms": round(float(np.median(lat)), 4),
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<Op,EPI_GELU> (encoder fc1: [B*257,768]x[768,3072] + bias + erf-GELU)",
+        "roofline": {"bound": "mfma", "kernel": "gemm256r_kernel<Op,EPI_GELU> (encoder fc1: [B*257,768]x[768,3072] + bias + erf-GELU)",
                      "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_unit": "bytes/launch (HBM-side, PMC: 2*FETCH_SIZE+WRITE_SIZE; algorithmic 510 MB)",
                      "launch_ms": round(dom_ms, 4), "launches_timed": dom[1],
                      "flops_per_launch": fl["fc1"] * B},
         "step_tflops": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12, 2),
@@ -194,7 +230,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, model.params)
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -83,6 +83,7 @@ struct GemmArgs {
   int lda = 0, ldw = 0;  // row strides (elements) of A and W; 0 = K
   int split_from = 0;    // RES only: logical tiles >= split_from are split along K into split_parts
   int split_parts = 0;   // workgroups that accumulate into x with f32 atomics (tail-round fix)
+  int no_dma_epilogue = 0;   // diagnostics: residual tile through registers instead of LDS-DMA
 };
 
 // Epilogue shared by both GEMM kernels.  acc[nt][mt]: lane holds column m = m_base + 16 mt + fr and rows
@@ -374,6 +375,78 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
 }
 
+// In-place residual epilogue of the ring kernel with the x tile PREFETCHED by LDS-DMA.  Loading x through
+// registers costs ~18 us per 256x256 tile (32 dependent 16-B round trips per lane interleaved with stores
+// that may alias them); here the tile comes in as four 64-row quarters of 64 KB through the (now idle) LDS
+// ring, two quarters in flight, each row one 1-KiB piece with its 16-B chunks XOR-swizzled by (row & 15) so
+// that the accumulator-layout reads (16 lanes = 16 different rows, same column chunk) are conflict-free.
+template <int MT>
+__device__ __forceinline__ void res_epilogue_dma(const f32x4 (&acc)[4][MT], const GemmArgs& g, char* smem, int m0,
+                                                 int n0, int wave, int lane) {
+  static_assert(MT == 8, "8-wave layout");
+  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
+  float* X = reinterpret_cast<float*>(g.out);
+  const bool edge = m0 + 256 > g.M;                 // some rows clamped / stores skipped: use full drains
+  f32x4 b4[4], l4[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    b4[nt] = *reinterpret_cast<const f32x4*>(g.bias + n0 + wn * 64 + nt * 16 + fq * 4);
+    l4[nt] = *reinterpret_cast<const f32x4*>(g.aux + n0 + wn * 64 + nt * 16 + fq * 4);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with the ring
+  auto dma_q = [&](int qi) {
+    char* dst = smem + (qi & 1) * 65536 + wave * 8192;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int p = wave * 8 + jj;                                          // local row 0..63 (wave-uniform)
+      int m = m0 + (p >> 5) * 128 + (2 * qi + ((p >> 4) & 1)) * 16 + (p & 15);
+      m = m < g.M ? m : g.M - 1;
+      const float* src = X + (size_t)m * g.N + n0 + ((lane ^ (p & 15)) << 2);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + jj * 1024), 16, 0, 0);
+    }
+  };
+  auto proc_q = [&](int qi) {
+    const char* lb = smem + (qi & 1) * 65536;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int mt = 2 * qi + u;
+      const int rl = wm * 32 + u * 16 + fr;
+      const int m = m0 + wm * 128 + mt * 16 + fr;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int c = wn * 16 + nt * 4 + fq;
+        f32x4 x = *reinterpret_cast<const f32x4*>(lb + rl * 1024 + ((c ^ fr) << 4));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = fmaf(acc[nt][mt][r] + b4[nt][r], l4[nt][r], x[r]);
+        if (m < g.M) *reinterpret_cast<f32x4*>(X + (size_t)m * g.N + n0 + wn * 64 + nt * 16 + fq * 4) = x;
+      }
+    }
+  };
+  dma_q(0);
+  dma_q(1);
+  // outstanding, oldest first: Q0 x8 | Q1 x8
+  if (edge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  proc_q(0);                                                                  // + 8 stores
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              // buffer 0 free
+  dma_q(2);
+  // Q1 x8 | st x8 | Q2 x8
+  if (edge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  proc_q(1);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              // buffer 1 free
+  dma_q(3);
+  // st x8 | Q2 x8 | st x8 | Q3 x8
+  if (edge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  proc_q(2);
+  // st x8 | Q3 x8 | st x8
+  if (edge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  proc_q(3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // gemm256r_kernel — the production 256x256 GEMM.  Measured on the simpler kernel above: with one K-tile
 // in flight the LDS-DMA side alone needs 1.36 us per 64-deep K-tile (latency-bound) and the MFMA side
@@ -553,6 +626,12 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
     if (nparts > 1) {
       gemm_epilogue_atomic<4, MT>(acc, g, m0 + wm * (16 * MT), n0 + wn * 64, fr, fq, part == 0);
       return;
+    }
+    if constexpr (WM == 2 && ABL == 0) {
+      if (!g.no_dma_epilogue) {
+        res_epilogue_dma<MT>(acc, g, smem, m0, n0, wave, lane);
+        return;
+      }
     }
   }
   gemm_epilogue<Op, EPI, 4, MT>(acc, g, m0 + wm * (16 * MT), n0 + wn * 64, fr, fq);
@@ -830,6 +909,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   }
   static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" force the older kernels
   static const bool nosplit = getenv("HVLA_NOSPLIT") != nullptr;
+  static const bool no_dma_epi = getenv("HVLA_NO_DMA_EPILOGUE") != nullptr;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -839,6 +919,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   auto gemm = [&](auto kern, auto kern256, auto kern256r, const void* A, const void* Wt, int Mm, int N, int K,
                   const float* bias, const float* aux, void* out, int qcols, bool is_res = false) {
     GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
+    a.no_dma_epilogue = no_dma_epi;
     const bool big = N % HBN_ == 0 && Mm >= 1024 && !(gsel && !strcmp(gsel, "128"));
     const bool fits32 = (size_t)Mm * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
     if (big && K >= 256 && fits32 && !(gsel && !strcmp(gsel, "simple"))) {

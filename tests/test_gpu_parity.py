@@ -199,3 +199,49 @@ def test_inference_wrapper_episode(full):
     for t in range(3):
         raw, act, img, (desc, task), dt = wr.step(full["im"][t % 4, 0])
         assert raw.shape == (7,) and act.shape == (7,) and act[-1] in (-1.0, 1.0) and dt > 0
+
+
+def test_hipgraph_replay_matches_eager(mid):
+    """hvla_step launches only on the given stream (no allocation / sync), so a step can be captured into a
+    hipGraph (BASELINE config 3) and replayed with new images in the same buffers."""
+    m, g, B = mid["model"], mid["g"], mid["B"]
+    w, _, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
+    dev = m.device
+    img = torch.as_tensor(mid["im"][:, 0]).to(dev).contiguous()
+    act = torch.empty(B, g.horizon, g.action_dim, device=dev)
+    lg = torch.empty(B, g.horizon, device=dev)
+    m._ctx.step(w._h, img.data_ptr(), act.data_ptr(), lg.data_ptr(), B, m._stream())
+    torch.cuda.synchronize()
+    eager = act.clone()
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        m._ctx.step(w._h, img.data_ptr(), act.data_ptr(), lg.data_ptr(), B, m._stream())
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            m._ctx.step(w._h, img.data_ptr(), act.data_ptr(), lg.data_ptr(), B, m._stream())
+    act.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(act, eager)
+    img.copy_(torch.flip(img, dims=[0]))               # new observations, same buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = act.clone()
+    m._ctx.step(w._h, img.data_ptr(), act.data_ptr(), lg.data_ptr(), B, m._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(replayed, act) and not torch.equal(replayed, eager)
+
+
+def test_bf16_encoder_option(mid):
+    """enc_dtype='bf16' (the north star's literal operand type) runs the same kernels with bf16 MFMA operands;
+    its measured error is ~8x the fp16 default's, which is why fp16 is the default."""
+    from hypervla.model import HyperVLA
+    m = HyperVLA.from_synthetic(mid["g"], max_batch=8, enc_dtype="bf16")
+    tok = m.encode_images(mid["im"]).cpu().numpy().astype(np.float64)
+    d = tok - mid["tok"]
+    rms = np.sqrt((d * d).mean())
+    assert 1e-4 < rms <= 2e-3, rms
+    w, tasks, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
+    act, _ = m.sample_actions(mid["im"], mid["ins"], tasks, None, w)
+    assert np.abs(act[..., :6] - mid["act"][..., :6]).mean() <= 8e-3
