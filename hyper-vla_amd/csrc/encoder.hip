@@ -461,8 +461,19 @@ __device__ __forceinline__ void res_epilogue_dma(const f32x4 (&acc)[4][MT], cons
 //     the first fragments of slot i+1 are fetched under that last group.
 // LDS rows are 64 B here; chunk' = chunk ^ LUT[(row >> 2) & 3], LUT = {0,2,3,1}, applied to the DMA source
 // address and to the read address, makes every ds_read_b128 lane group hit 16 distinct 16-B slots.
-template <typename Op, int EPI, int WM = 2, int ABL = 0>   // ABL (diagnostics): 1 no DMA in loop, 2 no MFMA, 3 DMA only
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {      // counted drain of the LDS-DMA queue (immediate operand)
+  static_assert(N >= 0 && N <= 17, "vmcnt immediate");
+#define HVLA_W(K) else if constexpr (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HVLA_W(1) HVLA_W(2) HVLA_W(3) HVLA_W(4) HVLA_W(5) HVLA_W(6) HVLA_W(7) HVLA_W(8) HVLA_W(9) HVLA_W(10) HVLA_W(11)
+  HVLA_W(12) HVLA_W(13) HVLA_W(14) HVLA_W(15) HVLA_W(16) HVLA_W(17)
+#undef HVLA_W
+}
+
+template <typename Op, int EPI, int WM = 2, int ABL = 0, int RING = 4>   // ABL (diagnostics): 1 no DMA in loop, 2 no MFMA, 3 DMA only
 __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
+  constexpr int D = RING - 1;                        // slots landed or in flight ahead of the one being consumed
   // WM waves along M x 4 along N; per-wave tile (256 / WM) x 64 = MT x 4 MFMA tiles.
   //   WM = 2:  8 waves, 128x64 per wave (128 accumulator VGPRs, 2 waves per SIMD)
   //   WM = 4: 16 waves,  64x64 per wave ( 64 accumulator VGPRs, 4 waves per SIMD: more issue interleave)
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
   static_assert(G == PPW, "one DMA piece per MFMA group");
   using T = typename Op::elem;
   using X8 = typename Op::x8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots x 32 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // RING slots x 32 KB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -488,10 +499,17 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
       bid = nfull + e / nparts;
     }
   }
+  // Tile order inside an XCD's contiguous id range: chunks of 8 M-tiles; inside a chunk the N super-columns
+  // (GN N-tiles each) one after the other.  The ~32 tiles an XCD runs at once are then an 8 x GN patch whose
+  // A and W K-slices share its 4 MiB L2, and the next patch reuses the SAME 8 A panels (still in L2), so the
+  // activation matrix is fetched from HBM once instead of once per super-column.
   const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
-  const int per_sc = nbm * GN;
-  const int sc = bid / per_sc, rem = bid % per_sc;
-  const int bm = rem / GN, bn = sc * GN + rem % GN;
+  constexpr int CH = 8;
+  const int per_chunk = CH * nbn;
+  const int chunk = bid / per_chunk, rc = bid % per_chunk;
+  const int rows = (nbm - chunk * CH) < CH ? (nbm - chunk * CH) : CH;      // last chunk may be short
+  const int sc = rc / (rows * GN), r2 = rc % (rows * GN);
+  const int bm = chunk * CH + r2 / GN, bn = sc * GN + r2 % GN;
   const int m0 = bm * HBM_, n0 = bn * HBN_;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
@@ -514,9 +532,9 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
     poff[j] += (uint32_t)(part * NP * 32);
   }
   auto dma = [&](int j, int slot_k /* phase index */) {
-    if (ABL == 1 && slot_k > 3) return;
+    if (ABL == 1 && slot_k > D) return;
     const int q = wave + NWV * j;                        // wave-uniform
-    char* dst = smem + (slot_k & 3) * 32768 + q * 1024;
+    char* dst = smem + (slot_k % RING) * 32768 + q * 1024;
     const T* src = (q < 16 ? A : W) + poff[j] + slot_k * 32;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -532,13 +550,13 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
   const int w_off = 16384 + (wn * 64 + fr) * 64 + ((fq ^ rlut) << 4);
   auto rd_a = [&](X8 (&fa)[2], int slot_k, int mp) {
     if (ABL == 3) return;
-    const char* lb = smem + (slot_k & 3) * 32768 + a_off + mp * 2048;
+    const char* lb = smem + (slot_k % RING) * 32768 + a_off + mp * 2048;
     fa[0] = *reinterpret_cast<const X8*>(lb);
     fa[1] = *reinterpret_cast<const X8*>(lb + 1024);
   };
   auto rd_w = [&](X8 (&fw)[4], int slot_k) {
     if (ABL == 3) return;
-    const char* lb = smem + (slot_k & 3) * 32768 + w_off;
+    const char* lb = smem + (slot_k % RING) * 32768 + w_off;
 #pragma unroll
     for (int t = 0; t < 4; ++t) fw[t] = *reinterpret_cast<const X8*>(lb + t * 1024);
   };
@@ -554,14 +572,13 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
       for (int nt = 0; nt < 4; ++nt) acc[nt][2 * mp + u] = Op::mma16(fw[nt], fa[u], acc[nt][2 * mp + u]);
   };
   X8 aA[2], aB[2], wA[4], wB[4];
-  // ---- prologue: slots 0,1,2 and the first piece of slot 3 in flight; slot 0 landed
+  // ---- prologue: slots 0..D-1 and the first piece of slot D in flight; slot 0 landed
 #pragma unroll
-  for (int sl = 0; sl < 3; ++sl)
+  for (int sl = 0; sl < D; ++sl)
 #pragma unroll
     for (int j = 0; j < PPW; ++j) dma(j, sl);
-  dma(0, 3);
-  if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  dma(0, D);
+  wait_vmcnt<(D - 1) * PPW + 1>();
   asm volatile("s_barrier" ::: "memory");
   rd_w(wA, 0);
   rd_a(aA, 0, 0);
@@ -578,28 +595,25 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
   if constexpr (NVM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);           \
   __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); /* 8 MFMA, this group     */
     rd_a(aB, i, 1);
-    if constexpr (MODE != 0) dma(1, i + 3);
+    if constexpr (MODE != 0) dma(1, i + D);
     mma_g(aA, wc, 0);
     HVLA_GRP(2, MODE != 0)
     if constexpr (G == 4) {
       rd_a(aA, i, 2);
-      if constexpr (MODE != 0) dma(2, i + 3);
+      if constexpr (MODE != 0) dma(2, i + D);
       mma_g(aB, wc, 1);
       HVLA_GRP(2, MODE != 0)
       rd_a(aB, i, 3);
-      if constexpr (MODE != 0) dma(3, i + 3);
+      if constexpr (MODE != 0) dma(3, i + D);
       mma_g(aA, wc, 2);
       HVLA_GRP(2, MODE != 0)
     }
     if constexpr (!LAST) {
-      if constexpr (VM * PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if constexpr (VM * PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if constexpr (VM * PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vmcnt<VM * PPW>();
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       rd_w(wnx, i + 1);
       rd_a(aA, i + 1, 0);
-      if constexpr (MODE == 1) dma(0, i + 4);
+      if constexpr (MODE == 1) dma(0, i + D + 1);
       mma_g(aB, wc, G - 1);
       HVLA_GRP(6, MODE == 1)
     } else {
@@ -612,16 +626,31 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
   using I2 = std::integral_constant<int, 2>;
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
+  using ID1 = std::integral_constant<int, D - 1>;
+  // NP is even (K % 64 == 0), phases go in (wA, wB) pairs; the tail is a fixed, branch-free sequence so that
+  // every register array keeps a static name (a run-time parity switch here spills 600 B per lane)
   int i = 0;
-  for (; i + 4 < NP; i += 2) {
-    phase(i, wA, wB, I1{}, I2{}, No{});
-    phase(i + 1, wB, wA, I1{}, I2{}, No{});
+  if constexpr (D == 3) {
+    for (; i + 4 < NP; i += 2) {
+      phase(i, wA, wB, I1{}, ID1{}, No{});
+      phase(i + 1, wB, wA, I1{}, ID1{}, No{});
+    }
+    phase(i, wA, wB, I2{}, I2{}, No{});          // NP-4: finish slot NP-1
+    phase(i + 1, wB, wA, I0{}, I1{}, No{});
+    phase(i + 2, wA, wB, I0{}, I0{}, No{});
+    phase(i + 3, wB, wA, I0{}, I0{}, Yes{});
+  } else {
+    for (; i + 6 < NP; i += 2) {
+      phase(i, wA, wB, I1{}, ID1{}, No{});
+      phase(i + 1, wB, wA, I1{}, ID1{}, No{});
+    }
+    phase(i, wA, wB, I1{}, ID1{}, No{});         // NP-6: last steady phase
+    phase(i + 1, wB, wA, I2{}, ID1{}, No{});     // NP-5: finish slot NP-1
+    phase(i + 2, wA, wB, I0{}, I2{}, No{});
+    phase(i + 3, wB, wA, I0{}, I1{}, No{});
+    phase(i + 4, wA, wB, I0{}, I0{}, No{});
+    phase(i + 5, wB, wA, I0{}, I0{}, Yes{});
   }
-  // tail: phases NP-4 .. NP-1
-  phase(i, wA, wB, I2{}, I2{}, No{});
-  phase(i + 1, wB, wA, I0{}, I1{}, No{});
-  phase(i + 2, wA, wB, I0{}, I0{}, No{});
-  phase(i + 3, wB, wA, I0{}, I0{}, Yes{});
   if constexpr (EPI == EPI_RES) {
     if (nparts > 1) {
       gemm_epilogue_atomic<4, MT>(acc, g, m0 + wm * (16 * MT), n0 + wn * 64, fr, fq, part == 0);
@@ -1028,7 +1057,7 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
       if (epi == EPI_QKV) L256R(EPI_QKV); else if (epi == EPI_GELU) L256R(EPI_GELU); else L256R(EPI_RES);
 #undef L256R
     } else if (variant == 4) {
-#define L256R4(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E, 4>), dim3(nb256), dim3(1024), 131072, st, a)
+#define L256R4(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E, 2, 0, 5>), dim3(nb256), dim3(512), 163840, st, a)
       if (epi == EPI_QKV) L256R4(EPI_QKV); else if (epi == EPI_GELU) L256R4(EPI_GELU); else L256R4(EPI_RES);
 #undef L256R4
     }
@@ -1044,9 +1073,9 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 0, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU, 2, 0, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES, 2, 0, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   launch();
