@@ -497,6 +497,17 @@ int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const fl
   return HVLA_OK;
 }
 
+int hvla_loss(hvla_ctx* ctx, const float* actions, const float* logits, const float* target, const uint8_t* tmask,
+              const uint8_t* amask, float* loss, int32_t B, void* stream) {
+  if (!ctx) return HVLA_E_STATE;
+  if (B < 1) FAIL(ctx, HVLA_E_SHAPE, "batch %d", B);
+  if (!actions || !logits || !target || !tmask || !amask || !loss) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, launch_loss(actions, logits, target, tmask, amask, loss, B, ctx->g.horizon, ctx->g.action_dim,
+                          ctx->g.max_action, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
 int hvla_profile(hvla_ctx* ctx, int32_t mode) {
   if (!ctx) return HVLA_E_STATE;
   if (mode < 0 || mode > 2) FAIL(ctx, HVLA_E_SHAPE, "profile mode %d", mode);

@@ -104,6 +104,10 @@ hipError_t launch_ensemble(const float* actions, float* ring, int* count, const 
                            const float* std, const uint8_t* mask, float* out, int B, int horizon,
                            int action_dim, hipStream_t st);
 
+hipError_t launch_loss(const float* actions, const float* logits, const float* target, const uint8_t* tmask,
+                       const uint8_t* amask, float* loss, int B, int horizon, int action_dim, float max_action,
+                       hipStream_t st);
+
 // ---------------------------------------------------------------- self test
 hipError_t launch_selftest(int* fail_flags, hipStream_t st);
 

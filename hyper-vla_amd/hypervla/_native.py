@@ -17,7 +17,7 @@ _ERRORS = {-1: "HVLA_E_SHAPE", -2: "HVLA_E_DTYPE", -3: "HVLA_E_DEVICE", -4: "HVL
 EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights", "hvla_num_generated",
            "hvla_generate", "hvla_weights_free", "hvla_weights_batch", "hvla_weights_export",
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
-           "hvla_selftest", "hvla_profile", "hvla_profile_read"]
+           "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy"]
 
 
@@ -79,6 +79,8 @@ def load_library():
     lib.hvla_ensemble_reset.restype = C.c_int
     lib.hvla_ensemble.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.hvla_ensemble.restype = C.c_int
+    lib.hvla_loss.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.hvla_loss.restype = C.c_int
     lib.hvla_profile.argtypes = [vp, i32]
     lib.hvla_profile.restype = C.c_int
     lib.hvla_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
@@ -177,6 +179,10 @@ class Context:
 
     def step(self, w, img_ptr, act_ptr, logit_ptr, B, stream=0):
         self._check(self.lib.hvla_step(self.h, w, img_ptr, act_ptr, logit_ptr, B, C.c_void_p(stream)), "hvla_step")
+
+    def loss(self, act_ptr, logit_ptr, target_ptr, tmask_ptr, amask_ptr, loss_ptr, B, stream=0):
+        self._check(self.lib.hvla_loss(self.h, act_ptr, logit_ptr, target_ptr, tmask_ptr, amask_ptr, loss_ptr, B,
+                                       C.c_void_p(stream)), "hvla_loss")
 
     def ensemble_reset(self, w, stream=0):
         self._check(self.lib.hvla_ensemble_reset(self.h, w, C.c_void_p(stream)), "hvla_ensemble_reset")

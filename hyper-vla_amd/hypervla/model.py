@@ -246,6 +246,25 @@ class HyperVLA:
         return actions, logits
 
 
+    def action_loss(self, actions, gripper_logits, batch):
+        """Per-sample MixActionHead.loss (action_heads.py:474-522) of policy outputs against an OXE batch
+        {"action" [B,1,H,7], "action_pad_mask" [B,1,H,7], "timestep_pad_mask" [B,1]}; returns (loss [B], mean)."""
+        torch = _torch()
+        g = self.geometry
+        act = self._dev(actions, torch.float32)
+        lg = self._dev(gripper_logits, torch.float32)
+        B = act.shape[0]
+        tgt = self._dev(np.asarray(batch["action"])[:, 0], torch.float32)
+        am = self._dev(np.asarray(batch["action_pad_mask"])[:, 0].astype(np.uint8), torch.uint8)
+        tm = self._dev(np.asarray(batch["timestep_pad_mask"])[:, 0].astype(np.uint8), torch.uint8)
+        if tuple(tgt.shape) != (B, g.horizon, g.action_dim) or tuple(lg.shape) != (B, g.horizon):
+            raise ValueError("bad loss shapes")
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        self._ctx.loss(act.data_ptr(), lg.data_ptr(), tgt.data_ptr(), tm.data_ptr(), am.data_ptr(), out.data_ptr(), B,
+                       self._stream())
+        return out, out.mean()
+
+
 HyperVLAModel = HyperVLA        # the name BASELINE.json's north_star uses
 
 

@@ -147,3 +147,14 @@ def synthetic_dataset_statistics(g: Geometry = FULL) -> Dict:
     p99 = (mean + 2.3 * std).astype(np.float32)
     stats = {"action": {"mean": mean, "std": std, "mask": mask, "p01": p01, "p99": p99}}
     return {"bridge_dataset": stats, "fractal20220817_data": stats, "libero": stats}
+
+
+def synthetic_action_batch(batch: int, g: Geometry = FULL, rank: int = 0) -> Dict:
+    """OXE-shaped training targets (octo/data/traj_transforms.py:11-99): action f32[B,1,H,7] (normalised, a few
+    beyond +-max_action so clip_target matters), action_pad_mask bool[B,1,H,7], timestep_pad_mask bool[B,1]."""
+    rng = _rng(6000 + rank)
+    a = rng.normal(0.0, 2.5, size=(batch, 1, g.horizon, g.action_dim)).astype(np.float32)
+    a[..., -1] = (rng.uniform(size=(batch, 1, g.horizon)) > 0.5).astype(np.float32)
+    apm = rng.uniform(size=a.shape) > 0.15
+    tpm = rng.uniform(size=(batch, 1)) > 0.1
+    return {"action": a, "action_pad_mask": apm, "timestep_pad_mask": tpm}

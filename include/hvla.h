@@ -120,6 +120,15 @@ int hvla_ensemble_reset(hvla_ctx* ctx, hvla_weights* w, void* stream);
 int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const float* mean,
                   const float* std, const uint8_t* mask, float* out, void* stream);
 
+/* Replaces: MixActionHead.loss evaluated per sample (vmap of sample_loss_fn) on the policy's outputs
+ * (hypervla/components/action_heads.py:474-522, scripts/train.py:326-346): the forward half of the
+ * fine-tune step.  actions / logits as written by hvla_policy / hvla_step; target f32 [B, horizon,
+ * action_dim] (clipped to +-max_action inside, clip_target=True); timestep_mask u8 [B];
+ * action_mask u8 [B, horizon, action_dim]; loss f32 [B] = 6 * masked-MSE + masked sigmoid-BCE.     */
+int hvla_loss(hvla_ctx* ctx, const float* actions, const float* gripper_logits, const float* target,
+              const uint8_t* timestep_mask, const uint8_t* action_mask, float* loss, int32_t B,
+              void* stream);
+
 /* Live per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  *   mode 0: off (default);  1: only the dominant kernel (encoder fc1 GEMM);  2: every category.
  * hvla_profile_read synchronises the recorded events, adds their durations per category into

@@ -226,3 +226,40 @@ class FullRef:
     def sample_actions(self, theta, images_u8, quant=None):
         tokens = encode_images(self.enc, images_u8, self.dt)
         return self.pol(theta, tokens, quant) + (tokens,)
+
+
+# ---------------------------------------------------------------- A13: loss and its gradient (round-2 oracle)
+def mix_loss(g, cont, logits, actions, timestep_pad_mask, action_pad_mask, clip_target=True):
+    """Per-sample MixActionHead.loss (action_heads.py:474-522) and the batch mean (scripts/train.py:453-457)."""
+    a = torch.as_tensor(np.asarray(actions)).to(cont.dtype)
+    if clip_target:
+        a = a.clamp(-g.max_action, g.max_action)
+    a = a[:, 0]                                                       # window 1
+    m = (torch.as_tensor(np.asarray(timestep_pad_mask)).bool()[:, :, None, None]
+         & torch.as_tensor(np.asarray(action_pad_mask)).bool())[:, 0].to(cont.dtype)
+    sq = (cont - a[..., :-1]) ** 2
+    mc, md = m[..., :-1], m[..., -1]
+    cont_term = (sq * mc).mean((1, 2)) / mc.mean((1, 2)).clamp_min(1e-5)
+    bce = Fn.binary_cross_entropy_with_logits(logits, a[..., -1], reduction="none")
+    disc_term = (bce * md).mean(1) / md.mean(1).clamp_min(1e-5)
+    per = cont_term * (g.action_dim - 1) + disc_term
+    return per, per.mean()
+
+
+def train_loss_and_grads(params, g, leaves, instruction_dict, initial_state, tokens, batch, dtype=torch.float64):
+    """Loss and d(loss)/d(HN params) with the image encoder frozen (tokens given): autograd through
+    hypernetwork -> generated theta -> per-sample policy -> mix loss.  This is the gradient oracle for the
+    fine-tune step."""
+    hn = HyperNetRef(params, g, leaves, dtype)
+    names = sorted(hn.p)
+    for k in names:
+        hn.p[k] = hn.p[k].clone().requires_grad_(True)
+    hn.w_cat = torch.cat([hn.p[l.head_name + "/kernel"] for l in leaves], dim=1)
+    hn.b_cat = torch.cat([hn.p[l.head_name + "/bias"] for l in leaves], dim=0)
+    li = instruction_dict["language_instruction"]
+    ctx = hn.context(li["token_embedding"], li["attention_mask"], np.asarray(initial_state["patch_embeddings"])[:, 0])
+    theta = hn.generate(ctx)
+    act, logit, _ = PolicyRef(g, leaves)(theta, torch.as_tensor(np.asarray(tokens)).to(dtype))
+    per, loss = mix_loss(g, act[..., :-1], logit, batch["action"], batch["timestep_pad_mask"], batch["action_pad_mask"])
+    grads = torch.autograd.grad(loss, [hn.p[k] for k in names], allow_unused=True)
+    return per.detach(), loss.detach(), {k: (gr.detach() if gr is not None else torch.zeros_like(hn.p[k])) for k, gr in zip(names, grads)}

@@ -245,3 +245,19 @@ def test_bf16_encoder_option(mid):
     w, tasks, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
     act, _ = m.sample_actions(mid["im"], mid["ins"], tasks, None, w)
     assert np.abs(act[..., :6] - mid["act"][..., :6]).mean() <= 8e-3
+
+
+def test_action_loss_matches_oracle(mid):
+    """hvla_loss (A13 forward): per-sample 6*masked-MSE + masked BCE on the HIP path's own outputs."""
+    from hypervla import synthetic as syn
+    from oracle import hvla_ref_np as onp
+    m, g, B = mid["model"], mid["g"], mid["B"]
+    w, tasks, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
+    act, inter = m.sample_actions(mid["im"], mid["ins"], tasks, None, w)
+    batch = syn.synthetic_action_batch(B, g)
+    batch["timestep_pad_mask"][1] = False                      # a fully padded sample -> loss 0
+    per, mean = m.action_loss(act, inter["gripper_logits"], batch)
+    ref, ref_mean = onp.mix_loss(g, act[..., :6], inter["gripper_logits"], batch["action"], batch["timestep_pad_mask"],
+                                 batch["action_pad_mask"])
+    np.testing.assert_allclose(per.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+    assert ref[1] == 0.0 and abs(float(mean) - ref_mean) < 1e-4

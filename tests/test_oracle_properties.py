@@ -98,3 +98,33 @@ def test_unnormalise_respects_mask():
     out = onp.unnormalize(a, stats)
     np.testing.assert_allclose(out[:, :6], a[:, :6] * stats["std"][:6] + stats["mean"][:6])
     np.testing.assert_array_equal(out[:, 6], a[:, 6])
+
+
+def test_mix_loss_numpy_vs_torch_and_gradient_oracle():
+    """A13 forward: the two restatements of MixActionHead.loss agree; the autograd gradient oracle (round-2
+    fine-tune step) is consistent with a central finite difference of the float64 loss."""
+    import torch
+    from oracle import hvla_ref_torch as ot
+    P, ins, st, im = _inputs(3)
+    batch = syn.synthetic_action_batch(3, G)
+    bp, _ = onp.create_tasks(P, G, LEAVES, ins, st)
+    tok = onp.dinov2(P, G, ENC, onp.normalize_images(im[:, 0]))[:, 1:]
+    act, logit, _ = onp.policy(bp, G, tok)
+    per, mean = onp.mix_loss(G, act[..., :6], logit, batch["action"], batch["timestep_pad_mask"], batch["action_pad_mask"])
+    per_t, mean_t, grads = ot.train_loss_and_grads(P, G, LEAVES, ins, st, tok, batch)
+    np.testing.assert_allclose(per, per_t.numpy(), atol=1e-10)
+    assert abs(mean - float(mean_t)) < 1e-10 and np.isfinite(per).all() and (per > 0).all()
+    key = LEAVES[5].head_name + "/bias"              # a generated LayerNorm/bias leaf
+    idx = 3
+    eps = 1e-5
+    vals = []
+    for sgn in (+1, -1):
+        P2 = dict(P)
+        v = P[key].astype(np.float64).copy()
+        v[idx] += sgn * eps
+        P2[key] = v
+        bp2, _ = onp.create_tasks(P2, G, LEAVES, ins, st)
+        a2, l2, _ = onp.policy(bp2, G, tok)
+        vals.append(onp.mix_loss(G, a2[..., :6], l2, batch["action"], batch["timestep_pad_mask"], batch["action_pad_mask"])[1])
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - float(grads[key][idx])) <= 1e-6 * max(1.0, abs(fd))
