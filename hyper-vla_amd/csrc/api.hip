@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "layout.h"
+#include "train.h"
 
 using namespace hvla;
 
@@ -505,6 +506,46 @@ int hvla_loss(hvla_ctx* ctx, const float* actions, const float* logits, const fl
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, launch_loss(actions, logits, target, tmask, amask, loss, B, ctx->g.horizon, ctx->g.action_dim,
                           ctx->g.max_action, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_train_sizes(hvla_ctx* ctx, int32_t B, int64_t out[4]) {
+  if (!ctx || !out) return HVLA_E_STATE;
+  if (B < 1) FAIL(ctx, HVLA_E_SHAPE, "batch %d", B);
+  const TrainLayout L = make_train_layout(ctx->g);
+  out[0] = L.total; out[1] = L.G; out[2] = (int64_t)train_workspace_floats(ctx->g, B); out[3] = 0;
+  return HVLA_OK;
+}
+
+static TrainBuffers to_tb(const hvla_train_buffers* b) {
+  return TrainBuffers{b->params, b->grads, reinterpret_cast<__bf16*>(b->mu), b->nu, b->ema, b->theta, b->dtheta, b->work,
+                      b->loss, b->actions, b->logits, b->sqsum, b->wd_mask};
+}
+
+int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* tok, const int64_t* mask, const float* cls,
+                    const float* tokens, const float* target, const uint8_t* tmask, const uint8_t* amask, int32_t B,
+                    const hvla_train_hyper* hy, void* stream) {
+  if (!ctx || !buf || !hy) return HVLA_E_STATE;
+  if (B < 1) FAIL(ctx, HVLA_E_SHAPE, "batch %d", B);
+  if (!buf->params || !buf->grads || !buf->theta || !buf->dtheta || !buf->work || !buf->loss || !tok || !mask || !cls ||
+      !tokens || !target || !tmask || !amask)
+    FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  if (ctx->g.ctx_layers > 8 || ctx->g.L > 16) FAIL(ctx, HVLA_E_SHAPE, "too many layers for the training path");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const TrainLayout L = make_train_layout(ctx->g);
+  TrainInputs in{tok, mask, cls, tokens, target, tmask, amask};
+  TrainHyper hp{hy->lr, hy->b1, hy->b2, hy->eps, hy->weight_decay, hy->clip, hy->ema_decay, hy->step, hy->forward_only};
+  HIPCHK(ctx, train_step(ctx->g, L, to_tb(buf), in, B, hp, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_train_hyper* hy, void* stream) {
+  if (!ctx || !buf || !hy) return HVLA_E_STATE;
+  if (!buf->params || !buf->grads || !buf->mu || !buf->nu || !buf->sqsum) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const TrainLayout L = make_train_layout(ctx->g);
+  TrainHyper hp{hy->lr, hy->b1, hy->b2, hy->eps, hy->weight_decay, hy->clip, hy->ema_decay, hy->step, hy->forward_only};
+  HIPCHK(ctx, train_apply(L, to_tb(buf), hp, reinterpret_cast<hipStream_t>(stream)));
   return HVLA_OK;
 }
 

@@ -1,0 +1,664 @@
+// train.hip — fine-tune step of the hypernetwork (BASELINE config 5):
+//   forward + backward of  loss(params) = mean_b MixLoss(policy(theta_b(params), tokens_b), action_b)
+//   (scripts/train.py:326-346,453-460; hypervla/components/action_heads.py:474-522), fused
+//   clip-by-global-norm + AdamW (bf16 first moment) + EMA (octo/utils/train_utils.py:411-426,
+//   scripts/train.py:618-625).  The DINOv2 image encoder is FROZEN in this first version
+//   (`fine_tune_pretrained_image_encoder=False`, the reference's config default): its tokens come from
+//   hvla_encode; gradients flow to every hypernetwork parameter (73 output heads = W_cat / b_cat, the
+//   context encoder, the projections and position embeddings).
+//
+// Correctness-first f32 implementation: one generic strided/batched f32 GEMM kernel (per-episode weights
+// are just a batch stride into theta[B, G]) plus small LayerNorm / softmax / GELU / bias-gradient kernels,
+// sequenced by host code.  Activations are kept in a workspace; cheap things (LN output, GELU) are
+// recomputed in the backward pass.  Parity: every gradient leaf against autograd on the float64 CPU
+// restatement (tests/test_gpu_train.py).
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "train.h"
+
+namespace hvla {
+
+// ------------------------------------------------------------------------------------------------
+// generic batched GEMM  C[b0,b1] (+)= alpha * op(A)[b0,b1] * op(B)[b0,b1] (+ bias[b0][n])
+// ------------------------------------------------------------------------------------------------
+struct BG {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;          // nullable, indexed [n], batch stride sBias0
+  int M, N, K, lda, ldb, ldc;
+  long sA0, sA1, sB0, sB1, sC0, sC1, sBias0;
+  int nb1;                    // batch = blockIdx.z = b0 * nb1 + b1
+  float alpha;
+  int accumulate;             // 0 store, 1 C += (one writer per element), 2 atomic C += (batches share C)
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
+  __shared__ float As[16][65];
+  __shared__ float Bs[16][65];
+  const int b0 = blockIdx.z / g.nb1, b1 = blockIdx.z % g.nb1;
+  const float* A = g.A + b0 * g.sA0 + b1 * g.sA1;
+  const float* B = g.B + b0 * g.sB0 + b1 * g.sB1;
+  float* C = g.C + b0 * g.sC0 + b1 * g.sC1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, 4 x 4 outputs each
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+      int mm, kk;
+      if (TA) { mm = i & 63; kk = i >> 6; } else { kk = i & 15; mm = i >> 4; }
+      const int m = m0 + mm, k = k0 + kk;
+      float v = 0.f;
+      if (m < g.M && k < g.K) v = TA ? A[(long)k * g.lda + m] : A[(long)m * g.lda + k];
+      As[kk][mm] = v;
+    }
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+      int nn, kk;
+      if (TB) { kk = i & 15; nn = i >> 4; } else { nn = i & 63; kk = i >> 6; }
+      const int n = n0 + nn, k = k0 + kk;
+      float v = 0.f;
+      if (n < g.N && k < g.K) v = TB ? B[(long)n * g.ldb + k] : B[(long)k * g.ldb + n];
+      Bs[kk][nn] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i], b[i] = Bs[kk][tx * 4 + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  const float* bias = g.bias ? g.bias + b0 * g.sBias0 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= g.N) continue;
+      float v = g.alpha * acc[i][j] + (bias ? bias[n] : 0.f);
+      float* c = C + (long)m * g.ldc + n;
+      if (g.accumulate == 2) unsafeAtomicAdd(c, v);          // several batches reduce into one C
+      else *c = g.accumulate ? *c + v : v;
+    }
+  }
+}
+
+static void bgemm(hipStream_t st, bool ta, bool tb, const BG& g, int nb0) {
+  dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, nb0 * g.nb1);
+  if (!ta && !tb) hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, dim3(256), 0, st, g);
+  else if (!ta && tb) hipLaunchKernelGGL((bgemm_kernel<false, true>), grid, dim3(256), 0, st, g);
+  else if (ta && !tb) hipLaunchKernelGGL((bgemm_kernel<true, false>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((bgemm_kernel<true, true>), grid, dim3(256), 0, st, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// row kernels (one wave per row).  Rows are [nb][S][D]; per-row parameters come from p + b * pstride.
+// ------------------------------------------------------------------------------------------------
+__global__ void ln_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mean,
+                              float* __restrict__ rstd, const float* __restrict__ scale,
+                              const float* __restrict__ bias, long pstride, int rows, int S, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * D;
+  float s = 0.f, q = 0.f;
+  for (int c = lane; c < D; c += 64) { s += xr[c]; q += xr[c] * xr[c]; }
+  for (int o = 32; o; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  const float m = s / D, var = fmaxf(0.f, q / D - m * m), r = rsqrtf(var + 1e-6f);
+  const float* sc = scale + (long)(row / S) * pstride;
+  const float* bi = bias + (long)(row / S) * pstride;
+  for (int c = lane; c < D; c += 64) y[(long)row * D + c] = (xr[c] - m) * r * sc[c] + bi[c];
+  if (lane == 0) { mean[row] = m; rstd[row] = r; }
+}
+
+// dx (+)= LN backward; per-row contributions to dscale / dbias are accumulated with atomics into
+// dscale + b * pstride (per-episode parameters: pstride = G; shared parameters: pstride = 0).
+__global__ void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                              const float* __restrict__ rstd, const float* __restrict__ scale, float* __restrict__ dx,
+                              float* __restrict__ dscale, float* __restrict__ dbias, long pstride, int rows, int S,
+                              int D, int accumulate) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float m = mean[row], r = rstd[row];
+  const float* xr = x + (long)row * D;
+  const float* dyr = dy + (long)row * D;
+  const float* sc = scale + (long)(row / S) * pstride;
+  float s1 = 0.f, s2 = 0.f;                               // sum(dxhat), sum(dxhat * xhat)
+  for (int c = lane; c < D; c += 64) {
+    const float xh = (xr[c] - m) * r, dxh = dyr[c] * sc[c];
+    s1 += dxh; s2 += dxh * xh;
+  }
+  for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  float* ds = dscale + (long)(row / S) * pstride;
+  float* db = dbias + (long)(row / S) * pstride;
+  for (int c = lane; c < D; c += 64) {
+    const float xh = (xr[c] - m) * r, dxh = dyr[c] * sc[c];
+    const float v = r * (dxh - s1 / D - xh * s2 / D);
+    float* d = dx + (long)row * D + c;
+    *d = accumulate ? *d + v : v;
+    unsafeAtomicAdd(ds + c, dyr[c] * xh);
+    unsafeAtomicAdd(db + c, dyr[c]);
+  }
+}
+
+// masked softmax over the last dim of [nmat][R][Cc] in place.  mode 0: policy mask (rows < R-1 cannot see
+// column Cc-1, base_vit.py:209-214); mode 1: context mask (hypernetwork.py:149-181) from attn_mask[b][T].
+__global__ void softmax_fwd_kernel(float* __restrict__ p, int nmat, int R, int Cc, int mode,
+                                   const int64_t* __restrict__ am, int heads) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= nmat * R) return;
+  const int mat = row / R, q = row % R;
+  float* pr = p + (long)row * Cc;
+  auto keep = [&](int k) {
+    if (mode == 0) return !(q < R - 1 && k == Cc - 1);
+    const int T = Cc - 2;
+    if (k < T) return am[(long)(mat / heads) * T + k] != 0;
+    if (k == T) return true;
+    return q == T + 1;
+  };
+  float mx = -3.4e38f;
+  for (int k = lane; k < Cc; k += 64) if (keep(k)) mx = fmaxf(mx, pr[k]);
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int k = lane; k < Cc; k += 64) {
+    const float e = keep(k) ? __expf(pr[k] - mx) : 0.f;
+    pr[k] = e;
+    sum += e;
+  }
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float inv = 1.f / sum;
+  for (int k = lane; k < Cc; k += 64) pr[k] *= inv;
+}
+
+// ds = p * (dp - sum_k dp p), in place on dp
+__global__ void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int rows, int Cc) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* pr = p + (long)row * Cc;
+  float* dr = dp + (long)row * Cc;
+  float s = 0.f;
+  for (int k = lane; k < Cc; k += 64) s += pr[k] * dr[k];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int k = lane; k < Cc; k += 64) dr[k] = pr[k] * (dr[k] - s);
+}
+
+__device__ __forceinline__ float dgelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x), t = tanhf(u);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * k0 * (1.f + 3.f * k1 * x * x);
+}
+__global__ void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ g, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] = gelu_tanh(u[i]);
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ u, float* __restrict__ dg, long n) {   // dg -> du in place
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dg[i] *= dgelu_tanh(u[i]);
+}
+
+// column sums: out[b * ostride + n] += sum_{r < R} x[b][r][n]  (bias gradients; rows_used <= R rows counted)
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long ostride, int R, int rows_used,
+                              int N, int nb) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (n >= N || b >= nb) return;
+  float s = 0.f;
+  for (int r = 0; r < rows_used; ++r) s += x[((long)b * R + r) * N + n];
+  unsafeAtomicAdd(out + (long)b * ostride + n, s);
+}
+
+// x0 assembly: rows < P already hold tokens.Wp + bp; row P = 0; += pos  (base_vit.py:182-204)
+__global__ void x0_finish_kernel(float* __restrict__ x, const float* __restrict__ pos, long pstride, int S, int D, int nb) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nb * S * D) return;
+  const int c = (int)(i % D), t = (int)((i / D) % S), b = (int)(i / ((long)S * D));
+  const float base = t == S - 1 ? 0.f : x[i];
+  x[i] = base + pos[(long)b * pstride + (long)t * D + c];
+}
+__global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+// dst[b * dstride + i] += src[b * n + i]
+__global__ void add_strided_kernel(float* __restrict__ dst, long dstride, const float* __restrict__ src, long n, int nb) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nb * n) return;
+  dst[(i / n) * dstride + (i % n)] += src[i];
+}
+
+// mix head + loss, forward and backward for the action-token row (one thread block of 64 per episode).
+// e = LN_f(x[S-1]); z = e.Wc + bc (A values), l = e.Wd + bd (Hz); cont = tanh(z / ts) * ma.
+// Writes loss[b]; if dxrow != null also d/d(theta head leaves) and d/dx[S-1] for loss_total = mean_b loss[b].
+struct HeadP {
+  const float* x; long xstride;             // [B][S][D], row S-1 used
+  const float* theta; float* dtheta; long G;
+  int o_wc, o_bc, o_wd, o_bd, o_ns, o_nb;   // leaf offsets in theta
+  const float* target; const uint8_t* tmask; const uint8_t* amask;
+  float* loss; float* dxrow;                // [B][D]
+  float* actions; float* logits;            // optional outputs
+  int B, S, D, Hz, ad; float tanh_scale, max_action;
+};
+__global__ void head_loss_kernel(HeadP p) {
+  const int b = blockIdx.x, lane = threadIdx.x;            // 64 lanes, D == 64
+  __shared__ float e[64], xh[64], dz[32], sh[4];
+  const float* xr = p.x + (long)b * p.xstride + (long)(p.S - 1) * p.D;
+  const float* th = p.theta + (long)b * p.G;
+  float v = xr[lane], s = v, q = v * v;
+  for (int o = 32; o; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  const float m = s / 64.f, var = fmaxf(0.f, q / 64.f - m * m), r = rsqrtf(var + 1e-6f);
+  xh[lane] = (v - m) * r;
+  e[lane] = xh[lane] * th[p.o_ns + lane] + th[p.o_nb + lane];
+  __syncthreads();
+  const int A = p.Hz * (p.ad - 1), NO = A + p.Hz;
+  float z = 0.f;
+  if (lane < NO) {
+    const float* W = lane < A ? th + p.o_wc : th + p.o_wd;
+    const int n = lane < A ? lane : lane - A, ld = lane < A ? A : p.Hz;
+    for (int k = 0; k < 64; ++k) z = fmaf(e[k], W[k * ld + n], z);
+    z += lane < A ? th[p.o_bc + n] : th[p.o_bd + n];
+  }
+  // ---- loss terms
+  const bool tm = p.tmask[b] != 0;
+  float cs = 0.f, cm = 0.f, ds = 0.f, dm = 0.f, dzl = 0.f, mk = 0.f, pred = 0.f, tgt = 0.f;
+  if (lane < NO) {
+    int h, a;
+    if (lane < A) { h = lane / (p.ad - 1); a = lane % (p.ad - 1); } else { h = lane - A; a = p.ad - 1; }
+    const long o = ((long)b * p.Hz + h) * p.ad + a;
+    mk = (tm && p.amask[o]) ? 1.f : 0.f;
+    tgt = fminf(fmaxf(p.target[o], -p.max_action), p.max_action);
+    if (lane < A) {
+      pred = tanhf(z / p.tanh_scale) * p.max_action;
+      cs = (pred - tgt) * (pred - tgt) * mk; cm = mk;
+      if (p.actions) p.actions[o] = pred;
+    } else {
+      const float sp = log1pf(expf(-fabsf(z)));
+      ds = (tgt * (fmaxf(-z, 0.f) + sp) + (1.f - tgt) * (fmaxf(z, 0.f) + sp)) * mk; dm = mk;
+      if (p.actions) p.actions[o] = z >= 0.f ? 1.f : 0.f;
+      if (p.logits) p.logits[(long)b * p.Hz + h] = z;
+    }
+  }
+  for (int o = 32; o; o >>= 1) {
+    cs += __shfl_xor(cs, o, 64); cm += __shfl_xor(cm, o, 64); ds += __shfl_xor(ds, o, 64); dm += __shfl_xor(dm, o, 64);
+  }
+  const float nc = (float)A, nd = (float)p.Hz;
+  const float dc = fmaxf(cm / nc, 1e-5f), dd = fmaxf(dm / nd, 1e-5f);
+  if (lane == 0) p.loss[b] = (cs / nc) / dc * (float)(p.ad - 1) + (ds / nd) / dd;
+  if (!p.dxrow) return;
+  // ---- backward (d/dz of loss[b] / B)
+  const float gb = 1.f / (float)p.B;
+  if (lane < A) {
+    const float t = pred / p.max_action;                                   // tanh(z / ts)
+    dzl = gb * (float)(p.ad - 1) / (nc * dc) * 2.f * (pred - tgt) * mk * p.max_action * (1.f - t * t) / p.tanh_scale;
+  } else if (lane < NO) {
+    const float sg = 1.f / (1.f + expf(-z));
+    dzl = gb / (nd * dd) * (sg - tgt) * mk;
+  }
+  if (lane < 32) dz[lane] = lane < NO ? dzl : 0.f;
+  __syncthreads();
+  float* dth = p.dtheta + (long)b * p.G;
+  if (lane < NO) {                                                           // bias grads
+    if (lane < A) dth[p.o_bc + lane] += dzl; else dth[p.o_bd + lane - A] += dzl;
+  }
+  // kernel grads dW[k][n] = e[k] dz[n]; de[k] = sum_n W[k][n] dz[n]   (lane = k)
+  float de = 0.f;
+  for (int n = 0; n < A; ++n) { dth[p.o_wc + lane * A + n] += e[lane] * dz[n]; de = fmaf(th[p.o_wc + lane * A + n], dz[n], de); }
+  for (int n = 0; n < p.Hz; ++n) { dth[p.o_wd + lane * p.Hz + n] += e[lane] * dz[A + n]; de = fmaf(th[p.o_wd + lane * p.Hz + n], dz[A + n], de); }
+  dth[p.o_ns + lane] += de * xh[lane];
+  dth[p.o_nb + lane] += de;
+  const float dxh = de * th[p.o_ns + lane];
+  float s1 = dxh, s2 = dxh * xh[lane];
+  for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  p.dxrow[(long)b * p.D + lane] = r * (dxh - s1 / 64.f - xh[lane] * s2 / 64.f);
+}
+
+// context-token assembly: rows t < T += pos_tok[t]; row T += pos_img; row T+1 = pos_layer (hypernetwork.py:112-145)
+__global__ void ctx_rows_kernel(float* __restrict__ x, const float* __restrict__ pos_tok, const float* __restrict__ pos_img,
+                                const float* __restrict__ pos_layer, int B, int T, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Sc = T + 2;
+  if (i >= (long)B * Sc * C) return;
+  const int c = (int)(i % C), t = (int)((i / C) % Sc);
+  if (t < T) x[i] += pos_tok[(long)t * C + c];
+  else if (t == T) x[i] += pos_img[c];
+  else x[i] = pos_layer[c];
+}
+__global__ void ctx_rows_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos_tok, float* __restrict__ dpos_img,
+                                    float* __restrict__ dpos_layer, float* __restrict__ db_tok, float* __restrict__ db_img,
+                                    int B, int T, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Sc = T + 2;
+  if (i >= (long)B * Sc * C) return;
+  const int c = (int)(i % C), t = (int)((i / C) % Sc);
+  const float v = dx[i];
+  if (t < T) { unsafeAtomicAdd(dpos_tok + (long)t * C + c, v); unsafeAtomicAdd(db_tok + c, v); }
+  else if (t == T) { unsafeAtomicAdd(dpos_img + c, v); unsafeAtomicAdd(db_img + c, v); }
+  else unsafeAtomicAdd(dpos_layer + c, v);
+}
+// ctx[b] = (LN(x_b) * scale + bias) * post   (encoder_norm on the layer-token row, hypernetwork.py:188-192)
+__global__ void ctx_final_fwd_kernel(const float* __restrict__ x, long xstride, float* __restrict__ xhat,
+                                     float* __restrict__ mean, float* __restrict__ rstd, const float* __restrict__ scale,
+                                     const float* __restrict__ bias, float* __restrict__ ctx, int B, int C, float post) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float* xr = x + (long)b * xstride;
+  float s = 0.f, q = 0.f;
+  for (int c = lane; c < C; c += 64) { s += xr[c]; q += xr[c] * xr[c]; }
+  for (int o = 32; o; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  const float m = s / C, var = fmaxf(0.f, q / C - m * m), r = rsqrtf(var + 1e-6f);
+  for (int c = lane; c < C; c += 64) {
+    const float xh = (xr[c] - m) * r;
+    xhat[(long)b * C + c] = xh;
+    ctx[(long)b * C + c] = (xh * scale[c] + bias[c]) * post;
+  }
+  if (lane == 0) { mean[b] = m; rstd[b] = r; }
+}
+__global__ void ctx_final_bwd_kernel(const float* __restrict__ x, long xstride, const float* __restrict__ dctx,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     const float* __restrict__ scale, float* __restrict__ dx, float* __restrict__ dscale,
+                                     float* __restrict__ dbias, int B, int C, float post) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float* xr = x + (long)b * xstride;
+  const float m = mean[b], r = rstd[b];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float xh = (xr[c] - m) * r, dy = dctx[(long)b * C + c] * post, dxh = dy * scale[c];
+    s1 += dxh; s2 += dxh * xh;
+  }
+  for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  for (int c = lane; c < C; c += 64) {
+    const float xh = (xr[c] - m) * r, dy = dctx[(long)b * C + c] * post, dxh = dy * scale[c];
+    dx[(long)b * xstride + c] += r * (dxh - s1 / C - xh * s2 / C);
+    unsafeAtomicAdd(dscale + c, dy * xh);
+    unsafeAtomicAdd(dbias + c, dy);
+  }
+}
+
+// dctx[b][c] += sum_g dtheta[b][g] W[c][g] over a chunk of g (split-K with atomics)
+__global__ void dctx_kernel(const float* __restrict__ dth, const float* __restrict__ W, float* __restrict__ dctx, int B,
+                            int C, long G, int chunk) {
+  const int b = blockIdx.y, c = threadIdx.x >> 6, lane = threadIdx.x & 63;      // 4 waves -> 4 c values per block.z
+  const int cc = blockIdx.z * 4 + c;
+  if (cc >= C) return;
+  const long g0 = (long)blockIdx.x * chunk, g1 = g0 + chunk < G ? g0 + chunk : G;
+  float s = 0.f;
+  for (long gI = g0 + lane; gI < g1; gI += 64) s = fmaf(dth[(long)b * G + gI], W[(long)cc * G + gI], s);
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) unsafeAtomicAdd(dctx + (long)b * C + cc, s);
+}
+
+// ---- optimizer ------------------------------------------------------------------------------------
+__global__ void sqsum_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, s);
+}
+// clip-by-global-norm -> AdamW (mu stored bf16, optax mu_dtype) -> EMA; wd applied on [wd_lo, wd_hi)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, __bf16* __restrict__ mu,
+                             float* __restrict__ nu, float* __restrict__ ema, long n, const float* __restrict__ sq,
+                             float clip, float lr, float b1, float b2, float eps, float wd, long wcat, long bcat, long G,
+                             const uint8_t* __restrict__ wd_mask, float bc1, float bc2, float ema_decay) {
+  const float norm = sqrtf(sq[0]);
+  const float sc = norm < clip ? 1.f : clip / norm;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * sc;
+    const float m = b1 * (float)mu[i] + (1.f - b1) * gi;
+    const float v = b2 * nu[i] + (1.f - b2) * gi * gi;
+    mu[i] = (__bf16)m;
+    nu[i] = v;
+    float upd = (m / bc1) / (sqrtf(v / bc2) + eps);
+    if (i >= wcat && wd_mask) {            // weight_decay_strategy v5: heads that generate base-net kernels
+      const long gidx = i >= bcat ? i - bcat : (i - wcat) % G;
+      if (wd_mask[gidx]) upd += wd * p[i];
+    }
+    const float pn = p[i] - lr * upd;
+    p[i] = pn;
+    if (ema) ema[i] = ema_decay * ema[i] + (1.f - ema_decay) * pn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host sequencing
+// ------------------------------------------------------------------------------------------------
+#define KL(kernel, grid, block, ...) hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__)
+static inline dim3 g1(long n, int bs = 256) { long b = (n + bs - 1) / bs; return dim3((unsigned)(b > 65535 ? 65535 : b)); }
+
+TrainLayout make_train_layout(const Geom& g) {
+  TrainLayout L;
+  long o = 0;
+  auto add = [&](long& slot, long n) { slot = o; o += n; };
+  const int C = g.C, F = g.ctx_mlp;
+  add(L.w_tok, (long)g.lang_dim * C); add(L.b_tok, C); add(L.w_img, (long)g.E * C); add(L.b_img, C);
+  add(L.pos_tok, (long)g.T * C); add(L.pos_img, C); add(L.pos_layer, C);
+  for (int l = 0; l < g.ctx_layers; ++l) {
+    TrainLayout::CL& c = L.layer[l];
+    add(c.ln0_s, C); add(c.ln0_b, C); add(c.ln1_s, C); add(c.ln1_b, C);
+    add(c.wq, (long)C * C); add(c.bq, C); add(c.wk, (long)C * C); add(c.bk, C); add(c.wv, (long)C * C); add(c.bv, C);
+    add(c.wo, (long)C * C); add(c.bo, C); add(c.w1, (long)C * F); add(c.b1, F); add(c.w2, (long)F * C); add(c.b2, C);
+  }
+  add(L.norm_s, C); add(L.norm_b, C);
+  L.G = generated_leaves(g).back().offset + generated_leaves(g).back().size;
+  add(L.wcat, (long)C * L.G); add(L.bcat, L.G);
+  L.total = o;
+  return L;
+}
+
+struct Off { int wp, bp, pos, ns, nb, wc, bc, wd, bd; struct Lyr { int l0s, l0b, l1s, l1b, w1, b1, w2, b2, wk, bk, wo, bo, wq, bq, wv, bv; } l[16]; };
+static Off leaf_offsets(const Geom& g) {
+  Off o{};
+  auto lv = generated_leaves(g);
+  auto f = [&](const std::string& n) { for (auto& l : lv) if (l.flat == n) return (int)l.offset; return -1; };
+  o.bc = f("action_head_continuous_head_bias"); o.wc = f("action_head_continuous_head_kernel");
+  o.bd = f("action_head_discrete_head_bias"); o.wd = f("action_head_discrete_head_kernel");
+  o.nb = f("encoder_Transformer_0_encoder_norm_bias"); o.ns = f("encoder_Transformer_0_encoder_norm_scale");
+  o.bp = f("encoder_image_embedding_projection_bias"); o.wp = f("encoder_image_embedding_projection_kernel");
+  o.pos = f("encoder_pos_embedding");
+  for (int l = 0; l < g.L; ++l) {
+    const std::string B = "encoder_Transformer_0_encoderblock_" + std::to_string(l) + "_", A = B + "MultiHeadDotProductAttention_0_";
+    Off::Lyr& y = o.l[l];
+    y.l0b = f(B + "LayerNorm_0_bias"); y.l0s = f(B + "LayerNorm_0_scale"); y.l1b = f(B + "LayerNorm_1_bias"); y.l1s = f(B + "LayerNorm_1_scale");
+    y.b1 = f(B + "MlpBlock_0_Dense_0_bias"); y.w1 = f(B + "MlpBlock_0_Dense_0_kernel");
+    y.b2 = f(B + "MlpBlock_0_Dense_1_bias"); y.w2 = f(B + "MlpBlock_0_Dense_1_kernel");
+    y.bk = f(A + "key_bias"); y.wk = f(A + "key_kernel"); y.bo = f(A + "out_bias"); y.wo = f(A + "out_kernel");
+    y.bq = f(A + "query_bias"); y.wq = f(A + "query_kernel"); y.bv = f(A + "value_bias"); y.wv = f(A + "value_kernel");
+  }
+  return o;
+}
+
+// Transformer block forward / backward on rows [nb][S][D] with weights at W + b * wstride (wstride = G for
+// the per-episode policy, 0 for the shared context encoder).  Buffers for one layer:
+struct BlkBuf { float *x_in, *mean0, *rstd0, *q, *k, *v, *p, *o, *x_mid, *mean1, *rstd1, *u; };
+struct BlkW { const float *l0s, *l0b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *l1s, *l1b, *w1, *b1, *w2, *b2; };
+struct BlkG { float *l0s, *l0b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *l1s, *l1b, *w1, *b1, *w2, *b2; };
+
+static void block_fwd(hipStream_t st, int nb, int S, int D, int H, int F, long ws, const BlkW& w, const BlkBuf& a,
+                      float* x_out, float* tmp_h, float* tmp_g, int mask_mode, const int64_t* am) {
+  const int hd = D / H, rows = nb * S;
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, tmp_h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);
+  const float* Wm[3] = {w.wq, w.wk, w.wv};
+  const float* Bm[3] = {w.bq, w.bk, w.bv};
+  float* Om[3] = {a.q, a.k, a.v};
+  for (int i = 0; i < 3; ++i)
+    bgemm(st, false, false, BG{tmp_h, Wm[i], Om[i], Bm[i], S, D, D, D, D, D, (long)S * D, 0, ws, 0, (long)S * D, 0, ws, 1, 1.f, 0}, nb);
+  // scores[b][h] = q_h k_h^T / sqrt(hd)
+  bgemm(st, false, true, BG{a.q, a.k, a.p, nullptr, S, S, hd, D, D, S, (long)S * D, hd, (long)S * D, hd, (long)H * S * S, (long)S * S, 0, H, 1.f / sqrtf((float)hd), 0}, nb);
+  KL(softmax_fwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, nb * H, S, S, mask_mode, am, H);
+  bgemm(st, false, false, BG{a.p, a.v, a.o, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}, nb);
+  (void)hipMemcpyAsync(a.x_mid, a.x_in, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
+  bgemm(st, false, false, BG{a.o, w.wo, a.x_mid, w.bo, S, D, D, D, D, D, (long)S * D, 0, ws, 0, (long)S * D, 0, ws, 1, 1.f, 1}, nb);
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, tmp_h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);
+  bgemm(st, false, false, BG{tmp_h, w.w1, a.u, w.b1, S, F, D, D, F, F, (long)S * D, 0, ws, 0, (long)S * F, 0, ws, 1, 1.f, 0}, nb);
+  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, tmp_g, (long)rows * F);
+  (void)hipMemcpyAsync(x_out, a.x_mid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
+  bgemm(st, false, false, BG{tmp_g, w.w2, x_out, w.b2, S, D, F, F, D, D, (long)S * F, 0, ws, 0, (long)S * D, 0, ws, 1, 1.f, 1}, nb);
+}
+
+// dx (in/out: gradient wrt the block output on entry, wrt its input on exit).  Weight gradients: per-episode
+// (gs = G) written per b; shared (gs = 0) reduced over the batch by folding it into the GEMM's M/K dimension.
+static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long ws, long gs, const BlkW& w, const BlkG& gw,
+                      const BlkBuf& a, float* dx, float* t_h, float* t_g, float* t_d, float* t_dq, float* t_dk,
+                      float* t_dv, float* t_dp) {
+  const int hd = D / H, rows = nb * S;
+  const bool shared = gs == 0;
+  auto wgrad = [&](const float* X, int K, const float* dY, int N, float* dW) {   // dW[K][N] (+)= X^T dY
+    if (shared) bgemm(st, true, false, BG{X, dY, dW, nullptr, K, N, rows, K, N, N, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);
+    else bgemm(st, true, false, BG{X, dY, dW, nullptr, K, N, S, K, N, N, (long)S * K, 0, (long)S * N, 0, gs, 0, 0, 1, 1.f, 1}, nb);
+  };
+  auto bgrad = [&](const float* dY, int N, float* dB) {
+    if (shared) KL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(64), dY, dB, 0, rows, rows, N, 1);
+    else KL(colsum_kernel, dim3((N + 63) / 64, nb), dim3(64), dY, dB, gs, S, S, N, nb);
+  };
+  // ---- MLP: x_out = x_mid + gelu(LN1(x_mid) W1 + b1) W2 + b2
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t_h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);   // recompute h2
+  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, t_g, (long)rows * F);                                         // recompute g
+  wgrad(t_g, F, dx, D, gw.w2);
+  bgrad(dx, D, gw.b2);
+  bgemm(st, false, true, BG{dx, w.w2, t_d, nullptr, S, F, D, D, D, F, (long)S * D, 0, ws, 0, (long)S * F, 0, 0, 1, 1.f, 0}, nb);   // dg = dx W2^T
+  KL(gelu_bwd_kernel, g1((long)rows * F), dim3(256), a.u, t_d, (long)rows * F);                                         // du
+  wgrad(t_h, D, t_d, F, gw.w1);
+  bgrad(t_d, F, gw.b1);
+  bgemm(st, false, true, BG{t_d, w.w1, t_g, nullptr, S, D, F, F, F, D, (long)S * F, 0, ws, 0, (long)S * D, 0, 0, 1, 1.f, 0}, nb);  // dh2 -> t_g[rows][D]
+  KL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t_g, a.mean1, a.rstd1, w.l1s, dx, gw.l1s, gw.l1b, shared ? 0 : gs, rows, S, D, 1);
+  //   (dx now = gradient wrt x_mid)
+  // ---- attention: x_mid = x_in + o Wo + bo
+  wgrad(a.o, D, dx, D, gw.wo);
+  bgrad(dx, D, gw.bo);
+  bgemm(st, false, true, BG{dx, w.wo, t_d, nullptr, S, D, D, D, D, D, (long)S * D, 0, ws, 0, (long)S * D, 0, 0, 1, 1.f, 0}, nb);   // do
+  // dp = do_h v_h^T ; dv_h = p^T do_h
+  bgemm(st, false, true, BG{t_d, a.v, t_dp, nullptr, S, S, hd, D, D, S, (long)S * D, hd, (long)S * D, hd, (long)H * S * S, (long)S * S, 0, H, 1.f, 0}, nb);
+  bgemm(st, true, false, BG{a.p, t_d, t_dv, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}, nb);
+  KL(softmax_bwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, t_dp, nb * H * S, S);                                 // ds
+  const float sc = 1.f / sqrtf((float)hd);
+  bgemm(st, false, false, BG{t_dp, a.k, t_dq, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);   // dq = ds k / sqrt(hd)
+  bgemm(st, true, false, BG{t_dp, a.q, t_dk, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);    // dk = ds^T q / sqrt(hd)
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t_h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);      // recompute h
+  const float* dqkv[3] = {t_dq, t_dk, t_dv};
+  float* gWm[3] = {gw.wq, gw.wk, gw.wv};
+  float* gBm[3] = {gw.bq, gw.bk, gw.bv};
+  const float* Wm[3] = {w.wq, w.wk, w.wv};
+  for (int i = 0; i < 3; ++i) {
+    wgrad(t_h, D, dqkv[i], D, gWm[i]);
+    bgrad(dqkv[i], D, gBm[i]);
+    bgemm(st, false, true, BG{dqkv[i], Wm[i], t_g, nullptr, S, D, D, D, D, D, (long)S * D, 0, ws, 0, (long)S * D, 0, 0, 1, 1.f, i > 0}, nb);   // dh
+  }
+  KL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t_g, a.mean0, a.rstd0, w.l0s, dx, gw.l0s, gw.l0b, shared ? 0 : gs, rows, S, D, 1);
+}
+
+size_t train_workspace_floats(const Geom& g, int B) {
+  const long S = g.S(), D = g.D, H = g.H, F = g.M, Sc = g.T + 2, C = g.C, Hc = g.ctx_heads, Fc = g.ctx_mlp;
+  auto blk = [&](long nb, long s, long d, long h, long f) { return nb * (s * d * 6 + s * 4 + h * s * s + s * f); };
+  long n = blk(B, S, D, H, F) * g.L + blk(B, Sc, C, Hc, Fc) * g.ctx_layers;
+  n += (long)B * S * D * 2;                      // x_final (policy) + dx
+  n += (long)B * Sc * C * 2;                     // ctx x_final + dx
+  n += (long)B * S * (D * 5 + F * 2) + (long)B * H * S * S;        // policy temporaries
+  n += (long)B * Sc * (C * 5 + Fc * 2) + (long)B * Hc * Sc * Sc;   // ctx temporaries
+  n += (long)B * (g.L > 0 ? 1 : 1) * D + (long)B * C * 4 + 4 * B + 64;
+  return (size_t)n + 4096;
+}
+
+hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& tb, const TrainInputs& in, int B,
+                      const TrainHyper& hp, hipStream_t st) {
+  const int S = g.S(), P = g.P(), D = g.D, H = g.H, F = g.M, E = g.E;
+  const int Sc = g.T + 2, C = g.C, Hc = g.ctx_heads, Fc = g.ctx_mlp, T = g.T;
+  const long G = L.G;
+  const Off off = leaf_offsets(g);
+  float* ws = tb.work;
+  auto take = [&](long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
+  auto take_blk = [&](long nb, long s, long d, long h, long f) {
+    BlkBuf b; b.x_in = take(nb * s * d); b.mean0 = take(nb * s); b.rstd0 = take(nb * s); b.q = take(nb * s * d); b.k = take(nb * s * d);
+    b.v = take(nb * s * d); b.p = take(nb * h * s * s); b.o = take(nb * s * d); b.x_mid = take(nb * s * d); b.mean1 = take(nb * s);
+    b.rstd1 = take(nb * s); b.u = take(nb * s * f); return b;
+  };
+  std::vector<BlkBuf> pb(g.L), cb(g.ctx_layers);
+  for (auto& b : cb) b = take_blk(B, Sc, C, Hc, Fc);
+  for (auto& b : pb) b = take_blk(B, S, D, H, F);
+  float* cx_fin = take((long)B * Sc * C); float* cdx = take((long)B * Sc * C);
+  float* px_fin = take((long)B * S * D); float* pdx = take((long)B * S * D);
+  float* t_h = take((long)B * S * D), *t_g = take((long)B * S * F), *t_d = take((long)B * S * F);
+  float* t_dq = take((long)B * S * D), *t_dk = take((long)B * S * D), *t_dv = take((long)B * S * D), *t_dp = take((long)B * H * S * S);
+  float* c_h = take((long)B * Sc * C), *c_g = take((long)B * Sc * Fc), *c_d = take((long)B * Sc * Fc);
+  float* c_dq = take((long)B * Sc * C), *c_dk = take((long)B * Sc * C), *c_dv = take((long)B * Sc * C), *c_dp = take((long)B * Hc * Sc * Sc);
+  float* cmean = take(B), *crstd = take(B), *ctx = take((long)B * C), *dctx = take((long)B * C), *ctxn = take((long)B * C);
+  float* dxrow = take((long)B * D);
+  const float* Pm = tb.params;
+  float* Gm = tb.grads;
+  (void)hipMemsetAsync(Gm, 0, (size_t)L.total * 4, st);
+  (void)hipMemsetAsync(tb.dtheta, 0, (size_t)B * G * 4, st);
+
+  // =============================== context encoder forward (hypernetwork.py:99-197) ===============================
+  float* cx0 = cb.empty() ? cx_fin : cb[0].x_in;
+  // tokens: [B][T][lang] . Wt + bt + pos_t  (rows 0..T-1 of each episode's [Sc][C] block)
+  bgemm(st, false, false, BG{in.tok, Pm + L.w_tok, cx0, Pm + L.b_tok, T, C, g.lang_dim, g.lang_dim, C, C, (long)T * g.lang_dim, 0, 0, 0, (long)Sc * C, 0, 0, 1, 1.f, 0}, B);
+  bgemm(st, false, false, BG{in.cls, Pm + L.w_img, cx0 + (long)T * C, Pm + L.b_img, 1, C, E, E, C, C, (long)E, 0, 0, 0, (long)Sc * C, 0, 0, 1, 1.f, 0}, B);
+  KL(ctx_rows_kernel, g1((long)B * Sc * C), dim3(256), cx0, Pm + L.pos_tok, Pm + L.pos_img, Pm + L.pos_layer, B, T, C);
+  auto cw = [&](int l) { const TrainLayout::CL& c = L.layer[l]; return BlkW{Pm + c.ln0_s, Pm + c.ln0_b, Pm + c.wq, Pm + c.bq, Pm + c.wk, Pm + c.bk, Pm + c.wv, Pm + c.bv, Pm + c.wo, Pm + c.bo, Pm + c.ln1_s, Pm + c.ln1_b, Pm + c.w1, Pm + c.b1, Pm + c.w2, Pm + c.b2}; };
+  auto cg = [&](int l) { const TrainLayout::CL& c = L.layer[l]; return BlkG{Gm + c.ln0_s, Gm + c.ln0_b, Gm + c.wq, Gm + c.bq, Gm + c.wk, Gm + c.bk, Gm + c.wv, Gm + c.bv, Gm + c.wo, Gm + c.bo, Gm + c.ln1_s, Gm + c.ln1_b, Gm + c.w1, Gm + c.b1, Gm + c.w2, Gm + c.b2}; };
+  for (int l = 0; l < g.ctx_layers; ++l)
+    block_fwd(st, B, Sc, C, Hc, Fc, 0, cw(l), cb[l], l + 1 < g.ctx_layers ? cb[l + 1].x_in : cx_fin, c_h, c_g, 1, in.attn_mask);
+  // ctx = LN_f(x[:, -1]) (/ sqrt(C)); rows gathered through a stride: x = cx_fin + (Sc-1)*C, row stride Sc*C
+  KL(ctx_final_fwd_kernel, dim3((B + 3) / 4), dim3(256), cx_fin + (long)(Sc - 1) * C, (long)Sc * C, ctxn, cmean, crstd, Pm + L.norm_s, Pm + L.norm_b, ctx, B, C, g.scale_context ? 1.f / sqrtf((float)C) : 1.f);
+  // =============================== theta = ctx W_cat + b_cat (hypernetwork.py:205-233) ===============================
+  bgemm(st, false, false, BG{ctx, Pm + L.wcat, tb.theta, Pm + L.bcat, B, (int)G, C, C, (int)G, (int)G, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 0}, 1);
+  // =============================== policy forward with per-episode weights ===============================
+  const float* TH = tb.theta;
+  float* px0 = pb[0].x_in;
+  bgemm(st, false, false, BG{in.tokens, TH + off.wp, px0, TH + off.bp, P, D, E, E, D, D, (long)P * E, 0, G, 0, (long)S * D, 0, G, 1, 1.f, 0}, B);
+  KL(x0_finish_kernel, g1((long)B * S * D), dim3(256), px0, TH + off.pos, G, S, D, B);
+  auto pw = [&](int l, const float* b) { const Off::Lyr& y = off.l[l]; return BlkW{b + y.l0s, b + y.l0b, b + y.wq, b + y.bq, b + y.wk, b + y.bk, b + y.wv, b + y.bv, b + y.wo, b + y.bo, b + y.l1s, b + y.l1b, b + y.w1, b + y.b1, b + y.w2, b + y.b2}; };
+  auto pg = [&](int l, float* b) { const Off::Lyr& y = off.l[l]; return BlkG{b + y.l0s, b + y.l0b, b + y.wq, b + y.bq, b + y.wk, b + y.bk, b + y.wv, b + y.bv, b + y.wo, b + y.bo, b + y.l1s, b + y.l1b, b + y.w1, b + y.b1, b + y.w2, b + y.b2}; };
+  for (int l = 0; l < g.L; ++l)
+    block_fwd(st, B, S, D, H, F, G, pw(l, TH), pb[l], l + 1 < g.L ? pb[l + 1].x_in : px_fin, t_h, t_g, 0, nullptr);
+  // =============================== head + loss (+ backward seed) ===============================
+  (void)hipMemsetAsync(pdx, 0, (size_t)B * S * D * 4, st);
+  HeadP hpp{px_fin, (long)S * D, TH, tb.dtheta, G, off.wc, off.bc, off.wd, off.bd, off.ns, off.nb, in.target, in.tmask, in.amask,
+            tb.loss, hp.forward_only ? nullptr : dxrow, tb.actions, tb.logits, B, S, D, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
+  KL(head_loss_kernel, dim3(B), dim3(64), hpp);
+  if (hp.forward_only) return hipGetLastError();
+  KL(add_strided_kernel, g1((long)B * D), dim3(256), pdx + (long)(S - 1) * D, (long)S * D, dxrow, (long)D, B);
+  // =============================== policy backward ===============================
+  for (int l = g.L - 1; l >= 0; --l)
+    block_bwd(st, B, S, D, H, F, G, G, pw(l, TH), pg(l, tb.dtheta), pb[l], pdx, t_h, t_g, t_d, t_dq, t_dk, t_dv, t_dp);
+  // x0 = [tokens Wp + bp ; 0] + pos : dpos = dx0, dbp = sum_{t<P} dx0, dWp = tokens^T dx0[:P]
+  KL(add_strided_kernel, g1((long)B * S * D), dim3(256), tb.dtheta + off.pos, G, pdx, (long)S * D, B);
+  KL(colsum_kernel, dim3((D + 63) / 64, B), dim3(64), pdx, tb.dtheta + off.bp, G, S, P, D, B);
+  bgemm(st, true, false, BG{in.tokens, pdx, tb.dtheta + off.wp, nullptr, E, D, P, E, D, D, (long)P * E, 0, (long)S * D, 0, G, 0, 0, 1, 1.f, 1}, B);
+  // =============================== weight generation backward ===============================
+  bgemm(st, true, false, BG{ctx, tb.dtheta, Gm + L.wcat, nullptr, C, (int)G, B, C, (int)G, (int)G, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);   // dW_cat = ctx^T dtheta
+  KL(colsum_kernel, dim3((unsigned)((G + 63) / 64), 1), dim3(64), tb.dtheta, Gm + L.bcat, 0, B, B, (int)G, 1);                  // db_cat
+  (void)hipMemsetAsync(dctx, 0, (size_t)B * C * 4, st);
+  {
+    const int chunk = 8192;
+    KL(dctx_kernel, dim3((unsigned)((G + chunk - 1) / chunk), B, (C + 3) / 4), dim3(256), tb.dtheta, Pm + L.wcat, dctx, B, C, G, chunk);
+  }
+  // =============================== context encoder backward ===============================
+  (void)hipMemsetAsync(cdx, 0, (size_t)B * Sc * C * 4, st);
+  KL(ctx_final_bwd_kernel, dim3((B + 3) / 4), dim3(256), cx_fin + (long)(Sc - 1) * C, (long)Sc * C, dctx, cmean, crstd, Pm + L.norm_s, cdx + (long)(Sc - 1) * C, Gm + L.norm_s, Gm + L.norm_b, B, C, g.scale_context ? 1.f / sqrtf((float)C) : 1.f);
+  for (int l = g.ctx_layers - 1; l >= 0; --l)
+    block_bwd(st, B, Sc, C, Hc, Fc, 0, 0, cw(l), cg(l), cb[l], cdx, c_h, c_g, c_d, c_dq, c_dk, c_dv, c_dp);
+  // inputs: tokens rows -> w_tok, b_tok, pos_tok ; image row -> w_img, b_img, pos_img ; layer row -> pos_layer
+  KL(ctx_rows_bwd_kernel, g1((long)B * Sc * C), dim3(256), cdx, Gm + L.pos_tok, Gm + L.pos_img, Gm + L.pos_layer, Gm + L.b_tok, Gm + L.b_img, B, T, C);
+  bgemm(st, true, false, BG{in.tok, cdx, Gm + L.w_tok, nullptr, g.lang_dim, C, T, g.lang_dim, C, C, (long)T * g.lang_dim, 0, (long)Sc * C, 0, 0, 0, 0, 1, 1.f, 2}, B);
+  bgemm(st, true, false, BG{in.cls, cdx + (long)T * C, Gm + L.w_img, nullptr, E, C, 1, E, C, C, (long)E, 0, (long)Sc * C, 0, 0, 0, 0, 1, 1.f, 2}, B);
+  return hipGetLastError();
+}
+
+hipError_t train_apply(const TrainLayout& L, const TrainBuffers& tb, const TrainHyper& hp, hipStream_t st) {
+  (void)hipMemsetAsync(tb.sqsum, 0, 4, st);
+  KL(sqsum_kernel, dim3(1024), dim3(256), tb.grads, L.total, tb.sqsum);
+  const float t = (float)(hp.step + 1);
+  KL(adamw_kernel, dim3(2048), dim3(256), tb.params, tb.grads, tb.mu, tb.nu, hp.ema_decay > 0.f ? tb.ema : nullptr, L.total, tb.sqsum,
+     hp.clip, hp.lr, hp.b1, hp.b2, hp.eps, hp.weight_decay, L.wcat, L.bcat, L.G, tb.wd_mask,
+     1.f - powf(hp.b1, t), 1.f - powf(hp.b2, t), hp.ema_decay);
+  return hipGetLastError();
+}
+
+}  // namespace hvla

@@ -17,7 +17,8 @@ _ERRORS = {-1: "HVLA_E_SHAPE", -2: "HVLA_E_DTYPE", -3: "HVLA_E_DEVICE", -4: "HVL
 EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights", "hvla_num_generated",
            "hvla_generate", "hvla_weights_free", "hvla_weights_batch", "hvla_weights_export",
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
-           "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss"]
+           "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
+           "hvla_train_sizes", "hvla_train_step", "hvla_train_apply"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy"]
 
 
@@ -32,6 +33,16 @@ class hvla_config(C.Structure):
 
 class hvla_tensor_desc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class hvla_train_buffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("params", "grads", "mu", "nu", "ema", "theta", "dtheta", "work", "loss",
+                                          "actions", "logits", "sqsum", "wd_mask")]
+
+
+class hvla_train_hyper(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("lr", "b1", "b2", "eps", "weight_decay", "clip", "ema_decay")] + \
+               [("step", C.c_int32), ("forward_only", C.c_int32)]
 
 
 _lib = None
@@ -81,6 +92,13 @@ def load_library():
     lib.hvla_ensemble.restype = C.c_int
     lib.hvla_loss.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.hvla_loss.restype = C.c_int
+    lib.hvla_train_sizes.argtypes = [vp, i32, C.POINTER(i64)]
+    lib.hvla_train_sizes.restype = C.c_int
+    lib.hvla_train_step.argtypes = [vp, C.POINTER(hvla_train_buffers), vp, vp, vp, vp, vp, vp, vp, i32,
+                                    C.POINTER(hvla_train_hyper), vp]
+    lib.hvla_train_step.restype = C.c_int
+    lib.hvla_train_apply.argtypes = [vp, C.POINTER(hvla_train_buffers), C.POINTER(hvla_train_hyper), vp]
+    lib.hvla_train_apply.restype = C.c_int
     lib.hvla_profile.argtypes = [vp, i32]
     lib.hvla_profile.restype = C.c_int
     lib.hvla_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
@@ -183,6 +201,18 @@ class Context:
     def loss(self, act_ptr, logit_ptr, target_ptr, tmask_ptr, amask_ptr, loss_ptr, B, stream=0):
         self._check(self.lib.hvla_loss(self.h, act_ptr, logit_ptr, target_ptr, tmask_ptr, amask_ptr, loss_ptr, B,
                                        C.c_void_p(stream)), "hvla_loss")
+
+    def train_sizes(self, B):
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.hvla_train_sizes(self.h, B, out), "hvla_train_sizes")
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def train_step(self, buf, ptrs, B, hyper, stream=0):
+        self._check(self.lib.hvla_train_step(self.h, C.byref(buf), *ptrs, B, C.byref(hyper), C.c_void_p(stream)),
+                    "hvla_train_step")
+
+    def train_apply(self, buf, hyper, stream=0):
+        self._check(self.lib.hvla_train_apply(self.h, C.byref(buf), C.byref(hyper), C.c_void_p(stream)), "hvla_train_apply")
 
     def ensemble_reset(self, w, stream=0):
         self._check(self.lib.hvla_ensemble_reset(self.h, w, C.c_void_p(stream)), "hvla_ensemble_reset")

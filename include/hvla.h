@@ -129,6 +129,40 @@ int hvla_loss(hvla_ctx* ctx, const float* actions, const float* gripper_logits, 
               const uint8_t* timestep_mask, const uint8_t* action_mask, float* loss, int32_t B,
               void* stream);
 
+/* Replaces: one fine-tune step of the hypernetwork (scripts/train.py:405-542 `train_step_pmap` without the
+ * frozen T5 / initial-image encoders that feed it; octo/utils/train_utils.py:295-443 `create_optimizer`):
+ * forward + backward of mean_b MixLoss(policy(theta_b(params), tokens_b), action_b), then (hvla_train_apply)
+ * clip-by-global-norm -> AdamW with bf16 first moment and the v5 weight-decay mask -> EMA.  The image encoder is
+ * frozen in this version (`fine_tune_pretrained_image_encoder=False`): `tokens` come from hvla_encode.  Between the
+ * two calls the caller all-reduces `grads` over ranks (RCCL; scripts/train.py:460 `pmean`).
+ * Every buffer is DEVICE memory owned by the caller; the flat parameter order is make_train_layout()
+ * (csrc/train.hip) == hypervla.train.train_param_layout(); sizes from hvla_train_sizes.                  */
+typedef struct hvla_train_buffers {
+  float* params;           /* [n_params]                                                     */
+  float* grads;            /* [n_params]  written by hvla_train_step                          */
+  void* mu;                /* [n_params]  bf16 first moment                                   */
+  float* nu;               /* [n_params]                                                     */
+  float* ema;              /* [n_params] or NULL                                              */
+  float* theta;            /* [B, G]                                                         */
+  float* dtheta;           /* [B, G]                                                         */
+  float* work;             /* [workspace_floats]                                              */
+  float* loss;             /* [B] per-sample loss                                             */
+  float* actions;          /* [B, horizon, action_dim] or NULL                                */
+  float* logits;           /* [B, horizon] or NULL                                            */
+  float* sqsum;            /* [1] scratch for the global gradient norm                        */
+  const uint8_t* wd_mask;  /* [G] 1 where the generated leaf is a base-net kernel (v5 mask)   */
+} hvla_train_buffers;
+typedef struct hvla_train_hyper {
+  float lr, b1, b2, eps, weight_decay, clip, ema_decay;
+  int32_t step, forward_only;
+} hvla_train_hyper;
+int hvla_train_sizes(hvla_ctx* ctx, int32_t B, int64_t out[4]); /* n_params, G, workspace_floats, 0 */
+int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* token_embedding,
+                    const int64_t* attention_mask, const float* initial_cls, const float* tokens,
+                    const float* target, const uint8_t* timestep_mask, const uint8_t* action_mask, int32_t B,
+                    const hvla_train_hyper* hyper, void* stream);
+int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_train_hyper* hyper, void* stream);
+
 /* Live per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  *   mode 0: off (default);  1: only the dominant kernel (encoder fc1 GEMM);  2: every category.
  * hvla_profile_read synchronises the recorded events, adds their durations per category into
