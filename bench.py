@@ -73,6 +73,46 @@ def cpu_baseline(g, params, seconds=12.0, batch=8):
                       f"{dt:.1f} s)"}
 
 
+def finetune_bench(a, model, rank, world, use_dist):
+    """Config 5: one optimiser step per iteration on a per-GPU batch; `value` = samples/s over all ranks."""
+    from hypervla import synthetic as syn
+    from hypervla.dp import max_over_ranks, whole_job_rate
+    from hypervla.train import FineTuner
+    import torch.distributed as dist
+    g, B, dev = model.geometry, a.batch, model.device
+    ft = FineTuner(model, B)
+    ins, st = syn.synthetic_instructions(B, g, rank), syn.synthetic_initial_state(B, g, rank)
+    images = torch.as_tensor(syn.synthetic_images(B, g, rank)[:, 0]).to(dev).contiguous()
+    batch = syn.synthetic_action_batch(B, g, rank)
+    losses = []
+    for _ in range(a.warmup):
+        losses.append(float(ft.step(ins, st, images, batch)))
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = ft.step(ins, st, images, batch)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "finetune_samples_per_sec", "value": round(whole_job_rate(B, world, a.steps, elapsed), 2),
+            "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (policy/hypernet fwd+bwd) + " + a.enc_dtype + " (frozen encoder)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4] variant: fine-tune step with the image encoder frozen "
+                                   "(encode + fwd + bwd + grad all-reduce + clip/AdamW(bf16 mu)/EMA), hypernetwork "
+                                   "parameters only", "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}, RCCL all-reduce of {ft.n} f32 gradients"},
+            "loss_first": round(losses[0], 5) if losses else None, "loss_last": round(float(last), 5)}))
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +122,8 @@ def main():
     ap.add_argument("--enc-dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (BASELINE config 3)")
+    ap.add_argument("--finetune", action="store_true",
+                    help="BASELINE config 5 (frozen-encoder variant): encode + fwd + bwd + RCCL grad all-reduce + AdamW + EMA")
     a = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -101,6 +143,8 @@ def main():
     g, B = FULL, a.batch
     model = HyperVLA.from_synthetic(g, device=local, max_batch=B, enc_dtype=a.enc_dtype)
     dev = model.device
+    if a.finetune:
+        return finetune_bench(a, model, rank, world, use_dist)
     ins, st = syn.synthetic_instructions(B, g, rank), syn.synthetic_initial_state(B, g, rank)
     images = torch.as_tensor(syn.synthetic_images(B, g, rank)[:, 0]).to(dev).contiguous()   # resident in HBM
     ctx = model._ctx

@@ -101,3 +101,28 @@ def test_loss_decreases_over_steps(setup):
     for i in range(8):
         losses.append(float(ft.step(s["ins"], s["st"], s["im"], s["batch"], lr=1e-3)))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.timeout(900)
+def test_full_geometry_gradients(golden_dir):
+    """README geometry (vit_t policy on 256 DINOv2-base tokens, 201 500 generated parameters), B = 2."""
+    from hypervla import synthetic as syn
+    from hypervla.config import FULL, generated_leaves
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner, unpack_params
+    from oracle import hvla_ref_torch as ot
+    g, B = FULL, 2
+    model = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g)
+    batch = syn.synthetic_action_batch(B, g)
+    tok = np.random.default_rng(9).standard_normal((B, g.patches, g.enc_dim)).astype(np.float32)   # frozen-encoder tokens
+    params = {k: v for k, v in model.params.items() if not k.startswith("encoder_image_encoder_")}
+    per, loss, grads = ot.train_loss_and_grads(params, g, generated_leaves(g), ins, st, tok, batch)
+    ft = FineTuner(model, B)
+    got_loss = ft.forward_backward(ins, st, tok, batch).cpu().numpy()
+    np.testing.assert_allclose(got_loss, per.numpy(), rtol=3e-4, atol=3e-5)
+    got = unpack_params(g, ft.grads.cpu().numpy())
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    worst = max((np.abs(got[k].reshape(v.shape) - v.numpy()).max() / max(float(v.abs().max()), 1e-4 * gmax), k) for k, v in grads.items())
+    print("full geometry worst relative gradient error", worst)
+    assert worst[0] <= 3e-3, worst
