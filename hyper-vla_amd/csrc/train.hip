@@ -38,17 +38,23 @@ struct BG {
   int accumulate;             // 0 store, 1 C += (one writer per element), 2 atomic C += (batches share C)
 };
 
+// 64x64 output tile per workgroup, 4 waves x (32x32) on the exact-f32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, guide §3): lane l supplies A[i = l & 31][k = l >> 5] and
+// B[k = l >> 5][j = l & 31], so both operands are conflict-free row reads of the k-major LDS tiles.
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
-  __shared__ float As[16][65];
-  __shared__ float Bs[16][65];
+  __shared__ float As[16][64];
+  __shared__ float Bs[16][64];
   const int b0 = blockIdx.z / g.nb1, b1 = blockIdx.z % g.nb1;
   const float* A = g.A + b0 * g.sA0 + b1 * g.sA1;
   const float* B = g.B + b0 * g.sB0 + b1 * g.sB1;
   float* C = g.C + b0 * g.sC0 + b1 * g.sC1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, 4 x 4 outputs each
-  float acc[4][4] = {};
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1, col = lane & 31, half = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int k0 = 0; k0 < g.K; k0 += 16) {
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
       int mm, kk;
@@ -68,31 +74,22 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i], b[i] = Bs[kk][tx * 4 + i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-    }
+    for (int kk = 0; kk < 16; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + half][wm * 32 + col], Bs[kk + half][wn * 32 + col], acc, 0, 0, 0);
     __syncthreads();
   }
   const float* bias = g.bias ? g.bias + b0 * g.sBias0 : nullptr;
+  const int n = n0 + wn * 32 + col;
+  if (n >= g.N) return;
+  const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + crow(r, half);
     if (m >= g.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= g.N) continue;
-      float v = g.alpha * acc[i][j] + (bias ? bias[n] : 0.f);
-      float* c = C + (long)m * g.ldc + n;
-      if (g.accumulate == 2) unsafeAtomicAdd(c, v);          // several batches reduce into one C
-      else *c = g.accumulate ? *c + v : v;
-    }
+    const float v = g.alpha * acc[r] + bn;
+    float* c = C + (long)m * g.ldc + n;
+    if (g.accumulate == 2) unsafeAtomicAdd(c, v);          // several batches reduce into one C
+    else *c = g.accumulate ? *c + v : v;
   }
 }
 
@@ -206,13 +203,15 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ u, float* __restrict__
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dg[i] *= dgelu_tanh(u[i]);
 }
 
-// column sums: out[b * ostride + n] += sum_{r < R} x[b][r][n]  (bias gradients; rows_used <= R rows counted)
+// column sums: out[b * ostride + n] += sum_{r < rows_used} x[b][r][n]  (bias gradients).  blockIdx.z splits the rows
+// into chunks of 64 that are reduced with one atomic each, so long shared-parameter reductions stay parallel.
 __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long ostride, int R, int rows_used,
                               int N, int nb) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (n >= N || b >= nb) return;
+  const int r0 = blockIdx.z * 64, r1 = r0 + 64 < rows_used ? r0 + 64 : rows_used;
   float s = 0.f;
-  for (int r = 0; r < rows_used; ++r) s += x[((long)b * R + r) * N + n];
+  for (int r = r0; r < r1; ++r) s += x[((long)b * R + r) * N + n];
   unsafeAtomicAdd(out + (long)b * ostride + n, s);
 }
 
@@ -514,8 +513,8 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
     else bgemm(st, true, false, BG{X, dY, dW, nullptr, K, N, S, K, N, N, (long)S * K, 0, (long)S * N, 0, gs, 0, 0, 1, 1.f, 1}, nb);
   };
   auto bgrad = [&](const float* dY, int N, float* dB) {
-    if (shared) KL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(64), dY, dB, 0, rows, rows, N, 1);
-    else KL(colsum_kernel, dim3((N + 63) / 64, nb), dim3(64), dY, dB, gs, S, S, N, nb);
+    if (shared) KL(colsum_kernel, dim3((N + 63) / 64, 1, (rows + 63) / 64), dim3(64), dY, dB, 0, rows, rows, N, 1);
+    else KL(colsum_kernel, dim3((N + 63) / 64, nb, (S + 63) / 64), dim3(64), dY, dB, gs, S, S, N, nb);
   };
   // ---- MLP: x_out = x_mid + gelu(LN1(x_mid) W1 + b1) W2 + b2
   KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t_h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);   // recompute h2
@@ -629,11 +628,11 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
     block_bwd(st, B, S, D, H, F, G, G, pw(l, TH), pg(l, tb.dtheta), pb[l], pdx, t_h, t_g, t_d, t_dq, t_dk, t_dv, t_dp);
   // x0 = [tokens Wp + bp ; 0] + pos : dpos = dx0, dbp = sum_{t<P} dx0, dWp = tokens^T dx0[:P]
   KL(add_strided_kernel, g1((long)B * S * D), dim3(256), tb.dtheta + off.pos, G, pdx, (long)S * D, B);
-  KL(colsum_kernel, dim3((D + 63) / 64, B), dim3(64), pdx, tb.dtheta + off.bp, G, S, P, D, B);
+  KL(colsum_kernel, dim3((D + 63) / 64, B, (P + 63) / 64), dim3(64), pdx, tb.dtheta + off.bp, G, S, P, D, B);
   bgemm(st, true, false, BG{in.tokens, pdx, tb.dtheta + off.wp, nullptr, E, D, P, E, D, D, (long)P * E, 0, (long)S * D, 0, G, 0, 0, 1, 1.f, 1}, B);
   // =============================== weight generation backward ===============================
   bgemm(st, true, false, BG{ctx, tb.dtheta, Gm + L.wcat, nullptr, C, (int)G, B, C, (int)G, (int)G, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);   // dW_cat = ctx^T dtheta
-  KL(colsum_kernel, dim3((unsigned)((G + 63) / 64), 1), dim3(64), tb.dtheta, Gm + L.bcat, 0, B, B, (int)G, 1);                  // db_cat
+  KL(colsum_kernel, dim3((unsigned)((G + 63) / 64), 1, (B + 63) / 64), dim3(64), tb.dtheta, Gm + L.bcat, 0, B, B, (int)G, 1);                  // db_cat
   (void)hipMemsetAsync(dctx, 0, (size_t)B * C * 4, st);
   {
     const int chunk = 8192;
