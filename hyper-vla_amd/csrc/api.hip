@@ -509,32 +509,40 @@ int hvla_loss(hvla_ctx* ctx, const float* actions, const float* logits, const fl
   return HVLA_OK;
 }
 
-int hvla_train_sizes(hvla_ctx* ctx, int32_t B, int64_t out[4]) {
+int hvla_train_sizes(hvla_ctx* ctx, int32_t B, int32_t train_encoder, int64_t out[4]) {
   if (!ctx || !out) return HVLA_E_STATE;
   if (B < 1) FAIL(ctx, HVLA_E_SHAPE, "batch %d", B);
+  if (ctx->g.ctx_layers > 8 || ctx->g.L > 16 || ctx->g.enc_layers > 24) FAIL(ctx, HVLA_E_SHAPE, "too many layers for the training path");
   const TrainLayout L = make_train_layout(ctx->g);
-  out[0] = L.total; out[1] = L.G; out[2] = (int64_t)train_workspace_floats(ctx->g, B); out[3] = 0;
+  out[0] = L.total + (train_encoder ? L.enc_total : 0); out[1] = L.G;
+  out[2] = (int64_t)train_workspace_floats(ctx->g, B, train_encoder != 0); out[3] = L.total;
   return HVLA_OK;
 }
 
 static TrainBuffers to_tb(const hvla_train_buffers* b) {
   return TrainBuffers{b->params, b->grads, reinterpret_cast<__bf16*>(b->mu), b->nu, b->ema, b->theta, b->dtheta, b->work,
-                      b->loss, b->actions, b->logits, b->sqsum, b->wd_mask};
+                      b->loss, b->actions, b->logits, b->sqsum, b->wd_mask, b->params0};
+}
+static TrainHyper to_hp(const hvla_train_hyper* hy) {
+  return TrainHyper{hy->lr, hy->b1, hy->b2, hy->eps, hy->weight_decay, hy->clip, hy->ema_decay, hy->step, hy->forward_only,
+                    hy->base_lr, hy->base_weight_decay};
 }
 
 int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* tok, const int64_t* mask, const float* cls,
-                    const float* tokens, const float* target, const uint8_t* tmask, const uint8_t* amask, int32_t B,
-                    const hvla_train_hyper* hy, void* stream) {
+                    const float* tokens, const uint8_t* images, const float* target, const uint8_t* tmask,
+                    const uint8_t* amask, int32_t B, const hvla_train_hyper* hy, void* stream) {
   if (!ctx || !buf || !hy) return HVLA_E_STATE;
   if (B < 1) FAIL(ctx, HVLA_E_SHAPE, "batch %d", B);
   if (!buf->params || !buf->grads || !buf->theta || !buf->dtheta || !buf->work || !buf->loss || !tok || !mask || !cls ||
-      !tokens || !target || !tmask || !amask)
+      !target || !tmask || !amask)
     FAIL(ctx, HVLA_E_SHAPE, "null pointer");
-  if (ctx->g.ctx_layers > 8 || ctx->g.L > 16) FAIL(ctx, HVLA_E_SHAPE, "too many layers for the training path");
+  if ((tokens != nullptr) == (images != nullptr)) FAIL(ctx, HVLA_E_SHAPE, "pass exactly one of tokens (frozen encoder) / images (trained encoder)");
+  if ((images != nullptr) != (hy->train_encoder != 0)) FAIL(ctx, HVLA_E_STATE, "hyper.train_encoder does not match the inputs");
+  if (ctx->g.ctx_layers > 8 || ctx->g.L > 16 || ctx->g.enc_layers > 24) FAIL(ctx, HVLA_E_SHAPE, "too many layers for the training path");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const TrainLayout L = make_train_layout(ctx->g);
-  TrainInputs in{tok, mask, cls, tokens, target, tmask, amask};
-  TrainHyper hp{hy->lr, hy->b1, hy->b2, hy->eps, hy->weight_decay, hy->clip, hy->ema_decay, hy->step, hy->forward_only};
+  TrainInputs in{tok, mask, cls, tokens, images, target, tmask, amask};
+  const TrainHyper hp = to_hp(hy);
   HIPCHK(ctx, train_step(ctx->g, L, to_tb(buf), in, B, hp, reinterpret_cast<hipStream_t>(stream)));
   return HVLA_OK;
 }
@@ -544,8 +552,7 @@ int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_tr
   if (!buf->params || !buf->grads || !buf->mu || !buf->nu || !buf->sqsum) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const TrainLayout L = make_train_layout(ctx->g);
-  TrainHyper hp{hy->lr, hy->b1, hy->b2, hy->eps, hy->weight_decay, hy->clip, hy->ema_decay, hy->step, hy->forward_only};
-  HIPCHK(ctx, train_apply(L, to_tb(buf), hp, reinterpret_cast<hipStream_t>(stream)));
+  HIPCHK(ctx, train_apply(L, to_tb(buf), to_hp(hy), hy->train_encoder != 0, reinterpret_cast<hipStream_t>(stream)));
   return HVLA_OK;
 }
 

@@ -8,12 +8,16 @@
 namespace hvla {
 
 // flat layout of the trainable hypernetwork parameters (float32 elements)
+// `total` = the hypernetwork's own parameters; the shared DINOv2 leaves follow at [total, total + enc_total) when the
+// image encoder is trained too (`fine_tune_pretrained_image_encoder=True`), in hypervla.config.encoder_leaves order.
 struct TrainLayout {
   long w_tok, b_tok, w_img, b_img, pos_tok, pos_img, pos_layer, norm_s, norm_b, wcat, bcat, total, G;
   struct CL { long ln0_s, ln0_b, ln1_s, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2; } layer[8];
+  long e_cls, e_mask, e_pb, e_pk, e_pos, e_lnb, e_lns, enc_total;
+  struct EL { long kb, kk, qb, qk, vb, vk, ob, ok, ls1, ls2, f1b, f1k, f2b, f2k, n1b, n1s, n2b, n2s; } enc[24];
 };
 TrainLayout make_train_layout(const Geom& g);
-size_t train_workspace_floats(const Geom& g, int B);
+size_t train_workspace_floats(const Geom& g, int B, bool train_encoder);
 
 struct TrainBuffers {        // all device memory, owned by the caller
   float* params;             // [total]
@@ -28,13 +32,16 @@ struct TrainBuffers {        // all device memory, owned by the caller
   float* actions;            // [B, horizon, action_dim] or null
   float* logits;             // [B, horizon] or null
   float* sqsum;              // [1]
-  const uint8_t* wd_mask;    // [G] 1 where the generated leaf is a base-net kernel (weight_decay_strategy v5)
+  const uint8_t* wd_mask;    // [G] 1 where the generated leaf is a base-net kernel (weight_decay_strategy v5);
+                             //     followed by [enc_total] 1 on the shared "kernel" leaves when the encoder is trained
+  const float* params0;      // [enc_total] pretrained encoder weights for the delta decay (train.py:465-471) or null
 };
 struct TrainInputs {
   const float* tok;          // [B, T, lang_dim]
   const int64_t* attn_mask;  // [B, T]
   const float* cls;          // [B, E]
-  const float* tokens;       // [B, P, E]  frozen-encoder patch tokens (hvla_encode)
+  const float* tokens;       // [B, P, E]  frozen-encoder patch tokens (hvla_encode); null when `images` is given
+  const uint8_t* images;     // [B, H, W, 3] -> the encoder runs (and is differentiated) inside the step
   const float* target;       // [B, horizon, action_dim]
   const uint8_t* tmask;      // [B]
   const uint8_t* amask;      // [B, horizon, action_dim]
@@ -42,9 +49,10 @@ struct TrainInputs {
 struct TrainHyper {
   float lr, b1, b2, eps, weight_decay, clip, ema_decay;
   int step, forward_only;
+  float base_lr, base_weight_decay;      // optimizer group of the shared (DINOv2) leaves, train_utils.py:411-419
 };
 hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& tb, const TrainInputs& in, int B,
                       const TrainHyper& hp, hipStream_t st);
-hipError_t train_apply(const TrainLayout& L, const TrainBuffers& tb, const TrainHyper& hp, hipStream_t st);
+hipError_t train_apply(const TrainLayout& L, const TrainBuffers& tb, const TrainHyper& hp, bool train_encoder, hipStream_t st);
 
 }  // namespace hvla

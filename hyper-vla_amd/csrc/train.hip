@@ -145,12 +145,78 @@ __global__ void ln_bwd_kernel(const float* __restrict__ x, const float* __restri
     const float v = r * (dxh - s1 / D - xh * s2 / D);
     float* d = dx + (long)row * D + c;
     *d = accumulate ? *d + v : v;
-    unsafeAtomicAdd(ds + c, dyr[c] * xh);
-    unsafeAtomicAdd(db + c, dyr[c]);
+    if (dscale) {
+      unsafeAtomicAdd(ds + c, dyr[c] * xh);
+      unsafeAtomicAdd(db + c, dyr[c]);
+    }
   }
 }
 
-// masked softmax over the last dim of [nmat][R][Cc] in place.  mode 0: policy mask (rows < R-1 cannot see
+// shared LayerNorm parameters: dscale[c] += sum_r dy[r][c] xhat[r][c], dbias[c] += sum_r dy[r][c]; 64 rows per
+// block (blockIdx.y) reduced in registers, one atomic per (block, column) instead of one per element.
+__global__ void ln_pgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, float* __restrict__ dscale, float* __restrict__ dbias,
+                                int rows, int D) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= D) return;
+  const int r0 = blockIdx.y * 64, r1 = r0 + 64 < rows ? r0 + 64 : rows;
+  float a = 0.f, b = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float d = dy[(long)r * D + c];
+    a = fmaf(d, (x[(long)r * D + c] - mean[r]) * rstd[r], a);
+    b += d;
+  }
+  unsafeAtomicAdd(dscale + c, a);
+  unsafeAtomicAdd(dbias + c, b);
+}
+
+// LayerScale (DINOv2 layer_scale{1,2}.lambda1): out = res + ls (.) y
+__global__ void scale_add_kernel(float* __restrict__ out, const float* __restrict__ res, const float* __restrict__ y,
+                                 const float* __restrict__ ls, long n, int D) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = res[i] + ls[i % D] * y[i];
+}
+// backward: dy = dx (.) ls ; dls[c] += sum_r dx[r][c] y[r][c]  (row chunks of 64 as in ln_pgrad_kernel)
+__global__ void ls_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ y, const float* __restrict__ ls,
+                              float* __restrict__ dy, float* __restrict__ dls, int rows, int D) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= D) return;
+  const int r0 = blockIdx.y * 64, r1 = r0 + 64 < rows ? r0 + 64 : rows;
+  const float l = ls[c];
+  float a = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float d = dx[(long)r * D + c];
+    a = fmaf(d, y[(long)r * D + c], a);
+    dy[(long)r * D + c] = d * l;
+  }
+  unsafeAtomicAdd(dls + c, a);
+}
+
+// DINOv2 input side (base_vit.py:111-122 + HF Dinov2Embeddings): normalised patch matrix [B*P][p*p*3] in the flax
+// conv kernel's (dy, dx, c) order, then x[b][0] = cls + pos[0], x[b][1+t] = patch_t W + b + pos[1+t].
+__global__ void im2col_f32_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int B, int HW, int p) {
+  const int gp = HW / p, K = p * p * 3;
+  const long n = (long)B * gp * gp * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const long t = i / K;
+    const int px = (int)(t % gp), py = (int)((t / gp) % gp), b = (int)(t / ((long)gp * gp));
+    const int c = k % 3, dx = (k / 3) % p, dy = k / (3 * p);
+    const float mean = c == 0 ? 0.485f : c == 1 ? 0.456f : 0.406f, sd = c == 0 ? 0.229f : c == 1 ? 0.224f : 0.225f;
+    const uint8_t v = img[(((long)b * HW + py * p + dy) * HW + px * p + dx) * 3 + c];
+    out[i] = ((float)v / 255.f - mean) / sd;
+  }
+}
+__global__ void enc_x0_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int B,
+                              int S, int E) {
+  const long n = (long)B * S * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % E), t = (int)((i / E) % S);
+    x[i] = (t == 0 ? cls[c] : x[i]) + pos[(long)t * E + c];
+  }
+}
+
+// masked softmax over the last dim of [nmat][R][Cc] in place.  mode 2: no mask; mode 0: policy mask (rows < R-1 cannot see
 // column Cc-1, base_vit.py:209-214); mode 1: context mask (hypernetwork.py:149-181) from attn_mask[b][T].
 __global__ void softmax_fwd_kernel(float* __restrict__ p, int nmat, int R, int Cc, int mode,
                                    const int64_t* __restrict__ am, int heads) {
@@ -159,6 +225,7 @@ __global__ void softmax_fwd_kernel(float* __restrict__ p, int nmat, int R, int C
   const int mat = row / R, q = row % R;
   float* pr = p + (long)row * Cc;
   auto keep = [&](int k) {
+    if (mode == 2) return true;                                    // DINOv2 encoder: dense attention
     if (mode == 0) return !(q < R - 1 && k == Cc - 1);
     const int T = Cc - 2;
     if (k < T) return am[(long)(mat / heads) * T + k] != 0;
@@ -196,11 +263,18 @@ __device__ __forceinline__ float dgelu_tanh(float x) {
   const float u = k0 * (x + k1 * x * x * x), t = tanhf(u);
   return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * k0 * (1.f + 3.f * k1 * x * x);
 }
-__global__ void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ g, long n) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] = gelu_tanh(u[i]);
+// erf form (torch nn.GELU(), the DINOv2 MLP): exact erff here, the training path is f32 end to end
+__device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  return 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
-__global__ void gelu_bwd_kernel(const float* __restrict__ u, float* __restrict__ dg, long n) {   // dg -> du in place
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dg[i] *= dgelu_tanh(u[i]);
+__global__ void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ g, long n, int erf_form) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    g[i] = erf_form ? gelu_erf_exact(u[i]) : gelu_tanh(u[i]);
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ u, float* __restrict__ dg, long n, int erf_form) {   // dg -> du in place
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dg[i] *= erf_form ? dgelu_erf(u[i]) : dgelu_tanh(u[i]);
 }
 
 // column sums: out[b * ostride + n] += sum_{r < rows_used} x[b][r][n]  (bias gradients).  blockIdx.z splits the rows
@@ -425,6 +499,33 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// optimizer group "shared" (train_utils.py:414-419 + scripts/train.py:465-471): AdamW at base_lr, decay base_wd on the
+// leaves named *kernel* (mask), and -- as the reference does for every shared leaf when base_wd > 0 -- the update
+// gets + base_lr * base_wd * p0 (the pull back towards the pretrained weights p0).
+__global__ void adamw_shared_kernel(float* __restrict__ p, const float* __restrict__ g, __bf16* __restrict__ mu,
+                                    float* __restrict__ nu, float* __restrict__ ema, long n, const float* __restrict__ sq,
+                                    float clip, float lr, float b1, float b2, float eps, float wd,
+                                    const uint8_t* __restrict__ mask, const float* __restrict__ p0, float bc1, float bc2,
+                                    float ema_decay) {
+  const float norm = sqrtf(sq[0]);
+  const float sc = norm < clip ? 1.f : clip / norm;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * sc;
+    const float m = b1 * (float)mu[i] + (1.f - b1) * gi;
+    const float v = b2 * nu[i] + (1.f - b2) * gi * gi;
+    mu[i] = (__bf16)m;
+    nu[i] = v;
+    float upd = (m / bc1) / (sqrtf(v / bc2) + eps);
+    if (wd > 0.f) {
+      if (mask && mask[i]) upd += wd * p[i];
+      if (p0) upd -= wd * p0[i];
+    }
+    const float pn = p[i] - lr * upd;
+    p[i] = pn;
+    if (ema) ema[i] = ema_decay * ema[i] + (1.f - ema_decay) * pn;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host sequencing
 // ------------------------------------------------------------------------------------------------
@@ -448,6 +549,18 @@ TrainLayout make_train_layout(const Geom& g) {
   L.G = generated_leaves(g).back().offset + generated_leaves(g).back().size;
   add(L.wcat, (long)C * L.G); add(L.bcat, L.G);
   L.total = o;
+  // shared DINOv2 leaves, hypervla.config.encoder_leaves order, offsets relative to L.total
+  o = 0;
+  const long E = g.E, Fe = g.enc_mlp, Se = g.P() + 1;
+  add(L.e_cls, E); add(L.e_mask, E); add(L.e_pb, E); add(L.e_pk, (long)g.patch * g.patch * 3 * E); add(L.e_pos, Se * E);
+  for (int l = 0; l < g.enc_layers; ++l) {
+    TrainLayout::EL& y = L.enc[l];
+    add(y.kb, E); add(y.kk, E * E); add(y.qb, E); add(y.qk, E * E); add(y.vb, E); add(y.vk, E * E); add(y.ob, E); add(y.ok, E * E);
+    add(y.ls1, E); add(y.ls2, E); add(y.f1b, Fe); add(y.f1k, E * Fe); add(y.f2b, E); add(y.f2k, Fe * E);
+    add(y.n1b, E); add(y.n1s, E); add(y.n2b, E); add(y.n2s, E);
+  }
+  add(L.e_lnb, E); add(L.e_lns, E);
+  L.enc_total = o;
   return L;
 }
 
@@ -475,37 +588,60 @@ static Off leaf_offsets(const Geom& g) {
 
 // Transformer block forward / backward on rows [nb][S][D] with weights at W + b * wstride (wstride = G for
 // the per-episode policy, 0 for the shared context encoder).  Buffers for one layer:
-struct BlkBuf { float *x_in, *mean0, *rstd0, *q, *k, *v, *p, *o, *x_mid, *mean1, *rstd1, *u; };
-struct BlkW { const float *l0s, *l0b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *l1s, *l1b, *w1, *b1, *w2, *b2; };
-struct BlkG { float *l0s, *l0b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *l1s, *l1b, *w1, *b1, *w2, *b2; };
+struct BlkBuf { float *x_in, *mean0, *rstd0, *q, *k, *v, *p, *o, *x_mid, *mean1, *rstd1, *u, *y1, *y2; };
+struct BlkW { const float *l0s, *l0b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *l1s, *l1b, *w1, *b1, *w2, *b2, *ls1, *ls2; };
+struct BlkG { float *l0s, *l0b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *l1s, *l1b, *w1, *b1, *w2, *b2, *ls1, *ls2; };
+// block flavour: the flax Encoder1DBlock of the context encoder / generated policy (tanh GELU, masked attention) or the
+// HF Dinov2Layer (erf GELU, LayerScale on both residual branches, dense attention)
+struct BlkOpt { int mask_mode; const int64_t* am; int gelu_erf; };
+struct BlkTmp { float *h, *g, *d, *dq, *dk, *dv, *dp, *y; };
+
+// Y[nb][S][N] (+)= X[nb][S][K] W + bias with W per episode (ws = G) or shared (ws = 0: the batch folds into M, so
+// S = 257 does not pay a mostly empty 64-row tile per sample)
+static void linear(hipStream_t st, int nb, int S, long ws, const float* X, const float* W, const float* bias, float* Y, int K, int N, int acc) {
+  if (ws == 0) bgemm(st, false, false, BG{X, W, Y, bias, nb * S, N, K, K, N, N, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, acc}, 1);
+  else bgemm(st, false, false, BG{X, W, Y, bias, S, N, K, K, N, N, (long)S * K, 0, ws, 0, (long)S * N, 0, ws, 1, 1.f, acc}, nb);
+}
+// dX[nb][S][K] (+)= dY[nb][S][N] W^T
+static void linear_dx(hipStream_t st, int nb, int S, long ws, const float* dY, const float* W, float* dX, int K, int N, int acc) {
+  if (ws == 0) bgemm(st, false, true, BG{dY, W, dX, nullptr, nb * S, K, N, N, N, K, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, acc}, 1);
+  else bgemm(st, false, true, BG{dY, W, dX, nullptr, S, K, N, N, N, K, (long)S * N, 0, ws, 0, (long)S * K, 0, 0, 1, 1.f, acc}, nb);
+}
 
 static void block_fwd(hipStream_t st, int nb, int S, int D, int H, int F, long ws, const BlkW& w, const BlkBuf& a,
-                      float* x_out, float* tmp_h, float* tmp_g, int mask_mode, const int64_t* am) {
+                      float* x_out, const BlkTmp& t, const BlkOpt& op) {
   const int hd = D / H, rows = nb * S;
-  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, tmp_h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);
-  const float* Wm[3] = {w.wq, w.wk, w.wv};
-  const float* Bm[3] = {w.bq, w.bk, w.bv};
-  float* Om[3] = {a.q, a.k, a.v};
-  for (int i = 0; i < 3; ++i)
-    bgemm(st, false, false, BG{tmp_h, Wm[i], Om[i], Bm[i], S, D, D, D, D, D, (long)S * D, 0, ws, 0, (long)S * D, 0, ws, 1, 1.f, 0}, nb);
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t.h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);
+  linear(st, nb, S, ws, t.h, w.wq, w.bq, a.q, D, D, 0);
+  linear(st, nb, S, ws, t.h, w.wk, w.bk, a.k, D, D, 0);
+  linear(st, nb, S, ws, t.h, w.wv, w.bv, a.v, D, D, 0);
   // scores[b][h] = q_h k_h^T / sqrt(hd)
   bgemm(st, false, true, BG{a.q, a.k, a.p, nullptr, S, S, hd, D, D, S, (long)S * D, hd, (long)S * D, hd, (long)H * S * S, (long)S * S, 0, H, 1.f / sqrtf((float)hd), 0}, nb);
-  KL(softmax_fwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, nb * H, S, S, mask_mode, am, H);
+  KL(softmax_fwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, nb * H, S, S, op.mask_mode, op.am, H);
   bgemm(st, false, false, BG{a.p, a.v, a.o, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}, nb);
-  (void)hipMemcpyAsync(a.x_mid, a.x_in, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
-  bgemm(st, false, false, BG{a.o, w.wo, a.x_mid, w.bo, S, D, D, D, D, D, (long)S * D, 0, ws, 0, (long)S * D, 0, ws, 1, 1.f, 1}, nb);
-  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, tmp_h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);
-  bgemm(st, false, false, BG{tmp_h, w.w1, a.u, w.b1, S, F, D, D, F, F, (long)S * D, 0, ws, 0, (long)S * F, 0, ws, 1, 1.f, 0}, nb);
-  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, tmp_g, (long)rows * F);
-  (void)hipMemcpyAsync(x_out, a.x_mid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
-  bgemm(st, false, false, BG{tmp_g, w.w2, x_out, w.b2, S, D, F, F, D, D, (long)S * F, 0, ws, 0, (long)S * D, 0, ws, 1, 1.f, 1}, nb);
+  if (w.ls1) {
+    linear(st, nb, S, ws, a.o, w.wo, w.bo, a.y1, D, D, 0);
+    KL(scale_add_kernel, g1((long)rows * D), dim3(256), a.x_mid, a.x_in, a.y1, w.ls1, (long)rows * D, D);
+  } else {
+    (void)hipMemcpyAsync(a.x_mid, a.x_in, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
+    linear(st, nb, S, ws, a.o, w.wo, w.bo, a.x_mid, D, D, 1);
+  }
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t.h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);
+  linear(st, nb, S, ws, t.h, w.w1, w.b1, a.u, D, F, 0);
+  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, t.g, (long)rows * F, op.gelu_erf);
+  if (w.ls2) {
+    linear(st, nb, S, ws, t.g, w.w2, w.b2, a.y2, F, D, 0);
+    KL(scale_add_kernel, g1((long)rows * D), dim3(256), x_out, a.x_mid, a.y2, w.ls2, (long)rows * D, D);
+  } else {
+    (void)hipMemcpyAsync(x_out, a.x_mid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
+    linear(st, nb, S, ws, t.g, w.w2, w.b2, x_out, F, D, 1);
+  }
 }
 
 // dx (in/out: gradient wrt the block output on entry, wrt its input on exit).  Weight gradients: per-episode
 // (gs = G) written per b; shared (gs = 0) reduced over the batch by folding it into the GEMM's M/K dimension.
 static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long ws, long gs, const BlkW& w, const BlkG& gw,
-                      const BlkBuf& a, float* dx, float* t_h, float* t_g, float* t_d, float* t_dq, float* t_dk,
-                      float* t_dv, float* t_dp) {
+                      const BlkBuf& a, float* dx, const BlkTmp& t, const BlkOpt& op) {
   const int hd = D / H, rows = nb * S;
   const bool shared = gs == 0;
   auto wgrad = [&](const float* X, int K, const float* dY, int N, float* dW) {   // dW[K][N] (+)= X^T dY
@@ -516,82 +652,144 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
     if (shared) KL(colsum_kernel, dim3((N + 63) / 64, 1, (rows + 63) / 64), dim3(64), dY, dB, 0, rows, rows, N, 1);
     else KL(colsum_kernel, dim3((N + 63) / 64, nb, (S + 63) / 64), dim3(64), dY, dB, gs, S, S, N, nb);
   };
-  // ---- MLP: x_out = x_mid + gelu(LN1(x_mid) W1 + b1) W2 + b2
-  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t_h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);   // recompute h2
-  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, t_g, (long)rows * F);                                         // recompute g
-  wgrad(t_g, F, dx, D, gw.w2);
-  bgrad(dx, D, gw.b2);
-  bgemm(st, false, true, BG{dx, w.w2, t_d, nullptr, S, F, D, D, D, F, (long)S * D, 0, ws, 0, (long)S * F, 0, 0, 1, 1.f, 0}, nb);   // dg = dx W2^T
-  KL(gelu_bwd_kernel, g1((long)rows * F), dim3(256), a.u, t_d, (long)rows * F);                                         // du
-  wgrad(t_h, D, t_d, F, gw.w1);
-  bgrad(t_d, F, gw.b1);
-  bgemm(st, false, true, BG{t_d, w.w1, t_g, nullptr, S, D, F, F, F, D, (long)S * F, 0, ws, 0, (long)S * D, 0, 0, 1, 1.f, 0}, nb);  // dh2 -> t_g[rows][D]
-  KL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t_g, a.mean1, a.rstd1, w.l1s, dx, gw.l1s, gw.l1b, shared ? 0 : gs, rows, S, D, 1);
+  auto ln_bwd = [&](const float* x, const float* dy, const float* mean, const float* rstd, const float* sc, float* gs_, float* gb_) {
+    if (shared) {
+      KL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), x, dy, mean, rstd, sc, dx, (float*)nullptr, (float*)nullptr, 0, rows, S, D, 1);
+      KL(ln_pgrad_kernel, dim3((D + 63) / 64, (rows + 63) / 64), dim3(64), x, dy, mean, rstd, gs_, gb_, rows, D);
+    } else {
+      KL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), x, dy, mean, rstd, sc, dx, gs_, gb_, gs, rows, S, D, 1);
+    }
+  };
+  // ---- MLP: x_out = x_mid + [ls2 (.)] (gelu(LN1(x_mid) W1 + b1) W2 + b2)
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t.h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);   // recompute h2
+  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, t.g, (long)rows * F, op.gelu_erf);                           // recompute g
+  const float* dy = dx;
+  if (w.ls2) {
+    KL(ls_bwd_kernel, dim3((D + 63) / 64, (rows + 63) / 64), dim3(64), dx, a.y2, w.ls2, t.y, gw.ls2, rows, D);
+    dy = t.y;
+  }
+  wgrad(t.g, F, dy, D, gw.w2);
+  bgrad(dy, D, gw.b2);
+  linear_dx(st, nb, S, ws, dy, w.w2, t.d, F, D, 0);                                                                     // dg = dy W2^T
+  KL(gelu_bwd_kernel, g1((long)rows * F), dim3(256), a.u, t.d, (long)rows * F, op.gelu_erf);                           // du
+  wgrad(t.h, D, t.d, F, gw.w1);
+  bgrad(t.d, F, gw.b1);
+  linear_dx(st, nb, S, ws, t.d, w.w1, t.g, D, F, 0);                                                                    // dh2 -> t.g[rows][D]
+  ln_bwd(a.x_mid, t.g, a.mean1, a.rstd1, w.l1s, gw.l1s, gw.l1b);
   //   (dx now = gradient wrt x_mid)
-  // ---- attention: x_mid = x_in + o Wo + bo
-  wgrad(a.o, D, dx, D, gw.wo);
-  bgrad(dx, D, gw.bo);
-  bgemm(st, false, true, BG{dx, w.wo, t_d, nullptr, S, D, D, D, D, D, (long)S * D, 0, ws, 0, (long)S * D, 0, 0, 1, 1.f, 0}, nb);   // do
+  // ---- attention: x_mid = x_in + [ls1 (.)] (o Wo + bo)
+  dy = dx;
+  if (w.ls1) {
+    KL(ls_bwd_kernel, dim3((D + 63) / 64, (rows + 63) / 64), dim3(64), dx, a.y1, w.ls1, t.y, gw.ls1, rows, D);
+    dy = t.y;
+  }
+  wgrad(a.o, D, dy, D, gw.wo);
+  bgrad(dy, D, gw.bo);
+  linear_dx(st, nb, S, ws, dy, w.wo, t.d, D, D, 0);                                                                     // do
   // dp = do_h v_h^T ; dv_h = p^T do_h
-  bgemm(st, false, true, BG{t_d, a.v, t_dp, nullptr, S, S, hd, D, D, S, (long)S * D, hd, (long)S * D, hd, (long)H * S * S, (long)S * S, 0, H, 1.f, 0}, nb);
-  bgemm(st, true, false, BG{a.p, t_d, t_dv, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}, nb);
-  KL(softmax_bwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, t_dp, nb * H * S, S);                                 // ds
+  bgemm(st, false, true, BG{t.d, a.v, t.dp, nullptr, S, S, hd, D, D, S, (long)S * D, hd, (long)S * D, hd, (long)H * S * S, (long)S * S, 0, H, 1.f, 0}, nb);
+  bgemm(st, true, false, BG{a.p, t.d, t.dv, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}, nb);
+  KL(softmax_bwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, t.dp, nb * H * S, S);                                 // ds
   const float sc = 1.f / sqrtf((float)hd);
-  bgemm(st, false, false, BG{t_dp, a.k, t_dq, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);   // dq = ds k / sqrt(hd)
-  bgemm(st, true, false, BG{t_dp, a.q, t_dk, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);    // dk = ds^T q / sqrt(hd)
-  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t_h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);      // recompute h
-  const float* dqkv[3] = {t_dq, t_dk, t_dv};
+  bgemm(st, false, false, BG{t.dp, a.k, t.dq, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);   // dq = ds k / sqrt(hd)
+  bgemm(st, true, false, BG{t.dp, a.q, t.dk, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);    // dk = ds^T q / sqrt(hd)
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t.h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);      // recompute h
+  const float* dqkv[3] = {t.dq, t.dk, t.dv};
   float* gWm[3] = {gw.wq, gw.wk, gw.wv};
   float* gBm[3] = {gw.bq, gw.bk, gw.bv};
   const float* Wm[3] = {w.wq, w.wk, w.wv};
   for (int i = 0; i < 3; ++i) {
-    wgrad(t_h, D, dqkv[i], D, gWm[i]);
+    wgrad(t.h, D, dqkv[i], D, gWm[i]);
     bgrad(dqkv[i], D, gBm[i]);
-    bgemm(st, false, true, BG{dqkv[i], Wm[i], t_g, nullptr, S, D, D, D, D, D, (long)S * D, 0, ws, 0, (long)S * D, 0, 0, 1, 1.f, i > 0}, nb);   // dh
+    linear_dx(st, nb, S, ws, dqkv[i], Wm[i], t.g, D, D, i > 0);                                                         // dh
   }
-  KL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t_g, a.mean0, a.rstd0, w.l0s, dx, gw.l0s, gw.l0b, shared ? 0 : gs, rows, S, D, 1);
+  ln_bwd(a.x_in, t.g, a.mean0, a.rstd0, w.l0s, gw.l0s, gw.l0b);
 }
 
-size_t train_workspace_floats(const Geom& g, int B) {
+// ---- workspace plan (shared by the size query and the step so the two cannot drift) ----------------------------
+struct Plan {
+  std::vector<BlkBuf> cb, pb, eb;
+  float *cx_fin, *cdx, *px_fin, *pdx, *ex_fin, *edx, *eh, *patches;
+  BlkTmp t;
+  float *cmean, *crstd, *ctx, *dctx, *ctxn, *dxrow, *emean, *erstd;
+  long used;
+};
+static Plan make_plan(const Geom& g, int B, bool enc, float* base) {
+  Plan pl;
+  float* ws = base;
+  auto take = [&](long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
+  auto take_blk = [&](long nb, long s, long d, long h, long f, bool ls) {
+    BlkBuf b; b.x_in = take(nb * s * d); b.mean0 = take(nb * s); b.rstd0 = take(nb * s); b.q = take(nb * s * d); b.k = take(nb * s * d);
+    b.v = take(nb * s * d); b.p = take(nb * h * s * s); b.o = take(nb * s * d); b.x_mid = take(nb * s * d); b.mean1 = take(nb * s);
+    b.rstd1 = take(nb * s); b.u = take(nb * s * f);
+    b.y1 = ls ? take(nb * s * d) : nullptr; b.y2 = ls ? take(nb * s * d) : nullptr;
+    return b;
+  };
   const long S = g.S(), D = g.D, H = g.H, F = g.M, Sc = g.T + 2, C = g.C, Hc = g.ctx_heads, Fc = g.ctx_mlp;
-  auto blk = [&](long nb, long s, long d, long h, long f) { return nb * (s * d * 6 + s * 4 + h * s * s + s * f); };
-  long n = blk(B, S, D, H, F) * g.L + blk(B, Sc, C, Hc, Fc) * g.ctx_layers;
-  n += (long)B * S * D * 2;                      // x_final (policy) + dx
-  n += (long)B * Sc * C * 2;                     // ctx x_final + dx
-  n += (long)B * S * (D * 5 + F * 2) + (long)B * H * S * S;        // policy temporaries
-  n += (long)B * Sc * (C * 5 + Fc * 2) + (long)B * Hc * Sc * Sc;   // ctx temporaries
-  n += (long)B * (g.L > 0 ? 1 : 1) * D + (long)B * C * 4 + 4 * B + 64;
-  return (size_t)n + 4096;
+  const long Se = g.P() + 1, E = g.E, He = g.enc_heads, Fe = g.enc_mlp;
+  pl.cb.resize(g.ctx_layers); pl.pb.resize(g.L); pl.eb.resize(enc ? g.enc_layers : 0);
+  for (auto& b : pl.cb) b = take_blk(B, Sc, C, Hc, Fc, false);
+  for (auto& b : pl.pb) b = take_blk(B, S, D, H, F, false);
+  for (auto& b : pl.eb) b = take_blk(B, Se, E, He, Fe, true);
+  pl.cx_fin = take(B * Sc * C); pl.cdx = take(B * Sc * C);
+  pl.px_fin = take(B * S * D); pl.pdx = take(B * S * D);
+  pl.ex_fin = pl.edx = pl.eh = pl.patches = pl.emean = pl.erstd = nullptr;
+  if (enc) {
+    pl.ex_fin = take(B * Se * E); pl.edx = take(B * Se * E); pl.eh = take(B * Se * E);
+    pl.patches = take((long)B * g.P() * g.patch * g.patch * 3);
+    pl.emean = take(B * Se); pl.erstd = take(B * Se);
+  }
+  // temporaries are used by one transformer at a time: size them for the largest
+  auto mx = [&](long a, long b, long c) { c = enc ? c : 0; return a > b ? (a > c ? a : c) : (b > c ? b : c); };
+  const long rd = mx(B * S * D, B * Sc * C, B * Se * E), rf = mx(B * S * F, B * Sc * Fc, B * Se * Fe), hss = mx(B * H * S * S, B * Hc * Sc * Sc, B * He * Se * Se);
+  pl.t.h = take(rd); pl.t.g = take(rf); pl.t.d = take(rf); pl.t.dq = take(rd); pl.t.dk = take(rd); pl.t.dv = take(rd); pl.t.dp = take(hss);
+  pl.t.y = take(rd);
+  pl.cmean = take(B); pl.crstd = take(B); pl.ctx = take(B * C); pl.dctx = take(B * C); pl.ctxn = take(B * C);
+  pl.dxrow = take(B * D);
+  pl.used = ws - base;
+  return pl;
+}
+size_t train_workspace_floats(const Geom& g, int B, bool train_encoder) {
+  return (size_t)make_plan(g, B, train_encoder, nullptr).used + 64;
 }
 
 hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& tb, const TrainInputs& in, int B,
                       const TrainHyper& hp, hipStream_t st) {
   const int S = g.S(), P = g.P(), D = g.D, H = g.H, F = g.M, E = g.E;
   const int Sc = g.T + 2, C = g.C, Hc = g.ctx_heads, Fc = g.ctx_mlp, T = g.T;
+  const int Se = P + 1, He = g.enc_heads, Fe = g.enc_mlp, Kp = g.patch * g.patch * 3;
+  const bool enc = in.images != nullptr;
   const long G = L.G;
   const Off off = leaf_offsets(g);
-  float* ws = tb.work;
-  auto take = [&](long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
-  auto take_blk = [&](long nb, long s, long d, long h, long f) {
-    BlkBuf b; b.x_in = take(nb * s * d); b.mean0 = take(nb * s); b.rstd0 = take(nb * s); b.q = take(nb * s * d); b.k = take(nb * s * d);
-    b.v = take(nb * s * d); b.p = take(nb * h * s * s); b.o = take(nb * s * d); b.x_mid = take(nb * s * d); b.mean1 = take(nb * s);
-    b.rstd1 = take(nb * s); b.u = take(nb * s * f); return b;
-  };
-  std::vector<BlkBuf> pb(g.L), cb(g.ctx_layers);
-  for (auto& b : cb) b = take_blk(B, Sc, C, Hc, Fc);
-  for (auto& b : pb) b = take_blk(B, S, D, H, F);
-  float* cx_fin = take((long)B * Sc * C); float* cdx = take((long)B * Sc * C);
-  float* px_fin = take((long)B * S * D); float* pdx = take((long)B * S * D);
-  float* t_h = take((long)B * S * D), *t_g = take((long)B * S * F), *t_d = take((long)B * S * F);
-  float* t_dq = take((long)B * S * D), *t_dk = take((long)B * S * D), *t_dv = take((long)B * S * D), *t_dp = take((long)B * H * S * S);
-  float* c_h = take((long)B * Sc * C), *c_g = take((long)B * Sc * Fc), *c_d = take((long)B * Sc * Fc);
-  float* c_dq = take((long)B * Sc * C), *c_dk = take((long)B * Sc * C), *c_dv = take((long)B * Sc * C), *c_dp = take((long)B * Hc * Sc * Sc);
-  float* cmean = take(B), *crstd = take(B), *ctx = take((long)B * C), *dctx = take((long)B * C), *ctxn = take((long)B * C);
-  float* dxrow = take((long)B * D);
+  const Plan pl = make_plan(g, B, enc, tb.work);
+  const std::vector<BlkBuf>&cb = pl.cb, &pb = pl.pb, &eb = pl.eb;
+  float *cx_fin = pl.cx_fin, *cdx = pl.cdx, *px_fin = pl.px_fin, *pdx = pl.pdx;
+  float *cmean = pl.cmean, *crstd = pl.crstd, *ctx = pl.ctx, *dctx = pl.dctx, *ctxn = pl.ctxn, *dxrow = pl.dxrow;
+  const BlkTmp& t = pl.t;
   const float* Pm = tb.params;
   float* Gm = tb.grads;
-  (void)hipMemsetAsync(Gm, 0, (size_t)L.total * 4, st);
+  const float* Pe = Pm + L.total;          // shared DINOv2 leaves (only touched when enc)
+  float* Ge = Gm + L.total;
+  (void)hipMemsetAsync(Gm, 0, (size_t)(L.total + (enc ? L.enc_total : 0)) * 4, st);
   (void)hipMemsetAsync(tb.dtheta, 0, (size_t)B * G * 4, st);
+  const BlkOpt ctx_opt{1, in.attn_mask, 0}, pol_opt{0, nullptr, 0}, enc_opt{2, nullptr, 1};
+
+  // =============================== DINOv2 forward in f32, activations kept (HF Dinov2Model; base_vit.py:111-131) =====
+  auto ew = [&](int l, const float* b) { const TrainLayout::EL& y = L.enc[l]; return BlkW{b + y.n1s, b + y.n1b, b + y.qk, b + y.qb, b + y.kk, b + y.kb, b + y.vk, b + y.vb, b + y.ok, b + y.ob, b + y.n2s, b + y.n2b, b + y.f1k, b + y.f1b, b + y.f2k, b + y.f2b, b + y.ls1, b + y.ls2}; };
+  auto eg = [&](int l, float* b) { const TrainLayout::EL& y = L.enc[l]; return BlkG{b + y.n1s, b + y.n1b, b + y.qk, b + y.qb, b + y.kk, b + y.kb, b + y.vk, b + y.vb, b + y.ok, b + y.ob, b + y.n2s, b + y.n2b, b + y.f1k, b + y.f1b, b + y.f2k, b + y.f2b, b + y.ls1, b + y.ls2}; };
+  const float* tokens = in.tokens;         // [B][P][E] rows, episode stride tok_stride
+  long tok_stride = (long)P * E;
+  if (enc) {
+    float* ex0 = eb.empty() ? pl.ex_fin : eb[0].x_in;
+    KL(im2col_f32_kernel, g1((long)B * P * Kp), dim3(256), in.images, pl.patches, B, g.image_size, g.patch);
+    bgemm(st, false, false, BG{pl.patches, Pe + L.e_pk, ex0 + E, Pe + L.e_pb, P, E, Kp, Kp, E, E, (long)P * Kp, 0, 0, 0, (long)Se * E, 0, 0, 1, 1.f, 0}, B);
+    KL(enc_x0_kernel, g1((long)B * Se * E), dim3(256), ex0, Pe + L.e_cls, Pe + L.e_pos, B, Se, E);
+    for (int l = 0; l < g.enc_layers; ++l)
+      block_fwd(st, B, Se, E, He, Fe, 0, ew(l, Pe), eb[l], l + 1 < g.enc_layers ? eb[l + 1].x_in : pl.ex_fin, t, enc_opt);
+    KL(ln_fwd_kernel, dim3((B * Se + 3) / 4), dim3(256), pl.ex_fin, pl.eh, pl.emean, pl.erstd, Pe + L.e_lns, Pe + L.e_lnb, 0, B * Se, Se, E);
+    tokens = pl.eh + E;                    // drop the CLS row through the pointer: rows 1.. of every [Se][E] block
+    tok_stride = (long)Se * E;
+  }
 
   // =============================== context encoder forward (hypernetwork.py:99-197) ===============================
   float* cx0 = cb.empty() ? cx_fin : cb[0].x_in;
@@ -599,10 +797,10 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   bgemm(st, false, false, BG{in.tok, Pm + L.w_tok, cx0, Pm + L.b_tok, T, C, g.lang_dim, g.lang_dim, C, C, (long)T * g.lang_dim, 0, 0, 0, (long)Sc * C, 0, 0, 1, 1.f, 0}, B);
   bgemm(st, false, false, BG{in.cls, Pm + L.w_img, cx0 + (long)T * C, Pm + L.b_img, 1, C, E, E, C, C, (long)E, 0, 0, 0, (long)Sc * C, 0, 0, 1, 1.f, 0}, B);
   KL(ctx_rows_kernel, g1((long)B * Sc * C), dim3(256), cx0, Pm + L.pos_tok, Pm + L.pos_img, Pm + L.pos_layer, B, T, C);
-  auto cw = [&](int l) { const TrainLayout::CL& c = L.layer[l]; return BlkW{Pm + c.ln0_s, Pm + c.ln0_b, Pm + c.wq, Pm + c.bq, Pm + c.wk, Pm + c.bk, Pm + c.wv, Pm + c.bv, Pm + c.wo, Pm + c.bo, Pm + c.ln1_s, Pm + c.ln1_b, Pm + c.w1, Pm + c.b1, Pm + c.w2, Pm + c.b2}; };
-  auto cg = [&](int l) { const TrainLayout::CL& c = L.layer[l]; return BlkG{Gm + c.ln0_s, Gm + c.ln0_b, Gm + c.wq, Gm + c.bq, Gm + c.wk, Gm + c.bk, Gm + c.wv, Gm + c.bv, Gm + c.wo, Gm + c.bo, Gm + c.ln1_s, Gm + c.ln1_b, Gm + c.w1, Gm + c.b1, Gm + c.w2, Gm + c.b2}; };
+  auto cw = [&](int l) { const TrainLayout::CL& c = L.layer[l]; return BlkW{Pm + c.ln0_s, Pm + c.ln0_b, Pm + c.wq, Pm + c.bq, Pm + c.wk, Pm + c.bk, Pm + c.wv, Pm + c.bv, Pm + c.wo, Pm + c.bo, Pm + c.ln1_s, Pm + c.ln1_b, Pm + c.w1, Pm + c.b1, Pm + c.w2, Pm + c.b2, nullptr, nullptr}; };
+  auto cg = [&](int l) { const TrainLayout::CL& c = L.layer[l]; return BlkG{Gm + c.ln0_s, Gm + c.ln0_b, Gm + c.wq, Gm + c.bq, Gm + c.wk, Gm + c.bk, Gm + c.wv, Gm + c.bv, Gm + c.wo, Gm + c.bo, Gm + c.ln1_s, Gm + c.ln1_b, Gm + c.w1, Gm + c.b1, Gm + c.w2, Gm + c.b2, nullptr, nullptr}; };
   for (int l = 0; l < g.ctx_layers; ++l)
-    block_fwd(st, B, Sc, C, Hc, Fc, 0, cw(l), cb[l], l + 1 < g.ctx_layers ? cb[l + 1].x_in : cx_fin, c_h, c_g, 1, in.attn_mask);
+    block_fwd(st, B, Sc, C, Hc, Fc, 0, cw(l), cb[l], l + 1 < g.ctx_layers ? cb[l + 1].x_in : cx_fin, t, ctx_opt);
   // ctx = LN_f(x[:, -1]) (/ sqrt(C)); rows gathered through a stride: x = cx_fin + (Sc-1)*C, row stride Sc*C
   KL(ctx_final_fwd_kernel, dim3((B + 3) / 4), dim3(256), cx_fin + (long)(Sc - 1) * C, (long)Sc * C, ctxn, cmean, crstd, Pm + L.norm_s, Pm + L.norm_b, ctx, B, C, g.scale_context ? 1.f / sqrtf((float)C) : 1.f);
   // =============================== theta = ctx W_cat + b_cat (hypernetwork.py:205-233) ===============================
@@ -610,12 +808,12 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   // =============================== policy forward with per-episode weights ===============================
   const float* TH = tb.theta;
   float* px0 = pb[0].x_in;
-  bgemm(st, false, false, BG{in.tokens, TH + off.wp, px0, TH + off.bp, P, D, E, E, D, D, (long)P * E, 0, G, 0, (long)S * D, 0, G, 1, 1.f, 0}, B);
+  bgemm(st, false, false, BG{tokens, TH + off.wp, px0, TH + off.bp, P, D, E, E, D, D, tok_stride, 0, G, 0, (long)S * D, 0, G, 1, 1.f, 0}, B);
   KL(x0_finish_kernel, g1((long)B * S * D), dim3(256), px0, TH + off.pos, G, S, D, B);
-  auto pw = [&](int l, const float* b) { const Off::Lyr& y = off.l[l]; return BlkW{b + y.l0s, b + y.l0b, b + y.wq, b + y.bq, b + y.wk, b + y.bk, b + y.wv, b + y.bv, b + y.wo, b + y.bo, b + y.l1s, b + y.l1b, b + y.w1, b + y.b1, b + y.w2, b + y.b2}; };
-  auto pg = [&](int l, float* b) { const Off::Lyr& y = off.l[l]; return BlkG{b + y.l0s, b + y.l0b, b + y.wq, b + y.bq, b + y.wk, b + y.bk, b + y.wv, b + y.bv, b + y.wo, b + y.bo, b + y.l1s, b + y.l1b, b + y.w1, b + y.b1, b + y.w2, b + y.b2}; };
+  auto pw = [&](int l, const float* b) { const Off::Lyr& y = off.l[l]; return BlkW{b + y.l0s, b + y.l0b, b + y.wq, b + y.bq, b + y.wk, b + y.bk, b + y.wv, b + y.bv, b + y.wo, b + y.bo, b + y.l1s, b + y.l1b, b + y.w1, b + y.b1, b + y.w2, b + y.b2, nullptr, nullptr}; };
+  auto pg = [&](int l, float* b) { const Off::Lyr& y = off.l[l]; return BlkG{b + y.l0s, b + y.l0b, b + y.wq, b + y.bq, b + y.wk, b + y.bk, b + y.wv, b + y.bv, b + y.wo, b + y.bo, b + y.l1s, b + y.l1b, b + y.w1, b + y.b1, b + y.w2, b + y.b2, nullptr, nullptr}; };
   for (int l = 0; l < g.L; ++l)
-    block_fwd(st, B, S, D, H, F, G, pw(l, TH), pb[l], l + 1 < g.L ? pb[l + 1].x_in : px_fin, t_h, t_g, 0, nullptr);
+    block_fwd(st, B, S, D, H, F, G, pw(l, TH), pb[l], l + 1 < g.L ? pb[l + 1].x_in : px_fin, t, pol_opt);
   // =============================== head + loss (+ backward seed) ===============================
   (void)hipMemsetAsync(pdx, 0, (size_t)B * S * D * 4, st);
   HeadP hpp{px_fin, (long)S * D, TH, tb.dtheta, G, off.wc, off.bc, off.wd, off.bd, off.ns, off.nb, in.target, in.tmask, in.amask,
@@ -625,11 +823,28 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   KL(add_strided_kernel, g1((long)B * D), dim3(256), pdx + (long)(S - 1) * D, (long)S * D, dxrow, (long)D, B);
   // =============================== policy backward ===============================
   for (int l = g.L - 1; l >= 0; --l)
-    block_bwd(st, B, S, D, H, F, G, G, pw(l, TH), pg(l, tb.dtheta), pb[l], pdx, t_h, t_g, t_d, t_dq, t_dk, t_dv, t_dp);
+    block_bwd(st, B, S, D, H, F, G, G, pw(l, TH), pg(l, tb.dtheta), pb[l], pdx, t, pol_opt);
   // x0 = [tokens Wp + bp ; 0] + pos : dpos = dx0, dbp = sum_{t<P} dx0, dWp = tokens^T dx0[:P]
   KL(add_strided_kernel, g1((long)B * S * D), dim3(256), tb.dtheta + off.pos, G, pdx, (long)S * D, B);
   KL(colsum_kernel, dim3((D + 63) / 64, B, (P + 63) / 64), dim3(64), pdx, tb.dtheta + off.bp, G, S, P, D, B);
-  bgemm(st, true, false, BG{in.tokens, pdx, tb.dtheta + off.wp, nullptr, E, D, P, E, D, D, (long)P * E, 0, (long)S * D, 0, G, 0, 0, 1, 1.f, 1}, B);
+  bgemm(st, true, false, BG{tokens, pdx, tb.dtheta + off.wp, nullptr, E, D, P, E, D, D, tok_stride, 0, (long)S * D, 0, G, 0, 0, 1, 1.f, 1}, B);
+  // =============================== DINOv2 backward ===============================
+  if (enc) {
+    // d tokens_b = dx0_b[:P] Wp_b^T -> rows 1.. of the final-LayerNorm output gradient (CLS row gets none)
+    float* dh = t.y;                                                      // [B][Se][E]; t.y is free between blocks
+    (void)hipMemsetAsync(dh, 0, (size_t)B * Se * E * 4, st);
+    bgemm(st, false, true, BG{pdx, TH + off.wp, dh + E, nullptr, P, E, D, D, D, E, (long)S * D, 0, G, 0, (long)Se * E, 0, 0, 1, 1.f, 0}, B);
+    float* edx = pl.edx;
+    KL(ln_bwd_kernel, dim3((B * Se + 3) / 4), dim3(256), pl.ex_fin, dh, pl.emean, pl.erstd, Pe + L.e_lns, edx, (float*)nullptr, (float*)nullptr, 0, B * Se, Se, E, 0);
+    KL(ln_pgrad_kernel, dim3((E + 63) / 64, (B * Se + 63) / 64), dim3(64), pl.ex_fin, dh, pl.emean, pl.erstd, Ge + L.e_lns, Ge + L.e_lnb, B * Se, E);
+    for (int l = g.enc_layers - 1; l >= 0; --l)
+      block_bwd(st, B, Se, E, He, Fe, 0, 0, ew(l, Pe), eg(l, Ge), eb[l], edx, t, enc_opt);
+    // x0[b][0] = cls + pos[0]; x0[b][1+t] = patch_t Wk + bk + pos[1+t]
+    KL(colsum_kernel, dim3((Se * E + 63) / 64, 1, (B + 63) / 64), dim3(64), edx, Ge + L.e_pos, 0, B, B, Se * E, 1);       // dpos = sum_b dx0
+    (void)hipMemcpyAsync(Ge + L.e_cls, Ge + L.e_pos, (size_t)E * 4, hipMemcpyDeviceToDevice, st);                          // dcls = dpos[0]
+    KL(colsum_kernel, dim3((E + 63) / 64, 1, (P + 63) / 64), dim3(64), Ge + L.e_pos + E, Ge + L.e_pb, 0, P, P, E, 1);     // dbias = sum_{t>=1} dpos[t]
+    bgemm(st, true, false, BG{pl.patches, edx + E, Ge + L.e_pk, nullptr, Kp, E, P, Kp, E, E, (long)P * Kp, 0, (long)Se * E, 0, 0, 0, 0, 1, 1.f, 2}, B);
+  }
   // =============================== weight generation backward ===============================
   bgemm(st, true, false, BG{ctx, tb.dtheta, Gm + L.wcat, nullptr, C, (int)G, B, C, (int)G, (int)G, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);   // dW_cat = ctx^T dtheta
   KL(colsum_kernel, dim3((unsigned)((G + 63) / 64), 1, (B + 63) / 64), dim3(64), tb.dtheta, Gm + L.bcat, 0, B, B, (int)G, 1);                  // db_cat
@@ -642,7 +857,7 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   (void)hipMemsetAsync(cdx, 0, (size_t)B * Sc * C * 4, st);
   KL(ctx_final_bwd_kernel, dim3((B + 3) / 4), dim3(256), cx_fin + (long)(Sc - 1) * C, (long)Sc * C, dctx, cmean, crstd, Pm + L.norm_s, cdx + (long)(Sc - 1) * C, Gm + L.norm_s, Gm + L.norm_b, B, C, g.scale_context ? 1.f / sqrtf((float)C) : 1.f);
   for (int l = g.ctx_layers - 1; l >= 0; --l)
-    block_bwd(st, B, Sc, C, Hc, Fc, 0, 0, cw(l), cg(l), cb[l], cdx, c_h, c_g, c_d, c_dq, c_dk, c_dv, c_dp);
+    block_bwd(st, B, Sc, C, Hc, Fc, 0, 0, cw(l), cg(l), cb[l], cdx, t, ctx_opt);
   // inputs: tokens rows -> w_tok, b_tok, pos_tok ; image row -> w_img, b_img, pos_img ; layer row -> pos_layer
   KL(ctx_rows_bwd_kernel, g1((long)B * Sc * C), dim3(256), cdx, Gm + L.pos_tok, Gm + L.pos_img, Gm + L.pos_layer, Gm + L.b_tok, Gm + L.b_img, B, T, C);
   bgemm(st, true, false, BG{in.tok, cdx, Gm + L.w_tok, nullptr, g.lang_dim, C, T, g.lang_dim, C, C, (long)T * g.lang_dim, 0, (long)Sc * C, 0, 0, 0, 0, 1, 1.f, 2}, B);
@@ -650,13 +865,18 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   return hipGetLastError();
 }
 
-hipError_t train_apply(const TrainLayout& L, const TrainBuffers& tb, const TrainHyper& hp, hipStream_t st) {
+hipError_t train_apply(const TrainLayout& L, const TrainBuffers& tb, const TrainHyper& hp, bool train_encoder, hipStream_t st) {
+  const long n = L.total + (train_encoder ? L.enc_total : 0);
   (void)hipMemsetAsync(tb.sqsum, 0, 4, st);
-  KL(sqsum_kernel, dim3(1024), dim3(256), tb.grads, L.total, tb.sqsum);
+  KL(sqsum_kernel, dim3(1024), dim3(256), tb.grads, n, tb.sqsum);          // one global norm over both optimizer groups
   const float t = (float)(hp.step + 1);
+  const float bc1 = 1.f - powf(hp.b1, t), bc2 = 1.f - powf(hp.b2, t);
   KL(adamw_kernel, dim3(2048), dim3(256), tb.params, tb.grads, tb.mu, tb.nu, hp.ema_decay > 0.f ? tb.ema : nullptr, L.total, tb.sqsum,
-     hp.clip, hp.lr, hp.b1, hp.b2, hp.eps, hp.weight_decay, L.wcat, L.bcat, L.G, tb.wd_mask,
-     1.f - powf(hp.b1, t), 1.f - powf(hp.b2, t), hp.ema_decay);
+     hp.clip, hp.lr, hp.b1, hp.b2, hp.eps, hp.weight_decay, L.wcat, L.bcat, L.G, tb.wd_mask, bc1, bc2, hp.ema_decay);
+  if (train_encoder)
+    KL(adamw_shared_kernel, dim3(2048), dim3(256), tb.params + L.total, tb.grads + L.total, tb.mu + L.total, tb.nu + L.total,
+       hp.ema_decay > 0.f ? tb.ema + L.total : nullptr, L.enc_total, tb.sqsum, hp.clip, hp.base_lr, hp.b1, hp.b2, hp.eps,
+       hp.base_weight_decay, tb.wd_mask ? tb.wd_mask + L.G : nullptr, tb.params0, bc1, bc2, hp.ema_decay);
   return hipGetLastError();
 }
 

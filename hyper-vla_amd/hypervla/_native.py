@@ -37,12 +37,13 @@ class hvla_tensor_desc(C.Structure):
 
 class hvla_train_buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("params", "grads", "mu", "nu", "ema", "theta", "dtheta", "work", "loss",
-                                          "actions", "logits", "sqsum", "wd_mask")]
+                                          "actions", "logits", "sqsum", "wd_mask", "params0")]
 
 
 class hvla_train_hyper(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lr", "b1", "b2", "eps", "weight_decay", "clip", "ema_decay")] + \
-               [("step", C.c_int32), ("forward_only", C.c_int32)]
+               [("step", C.c_int32), ("forward_only", C.c_int32), ("base_lr", C.c_float),
+                ("base_weight_decay", C.c_float), ("train_encoder", C.c_int32)]
 
 
 _lib = None
@@ -92,9 +93,9 @@ def load_library():
     lib.hvla_ensemble.restype = C.c_int
     lib.hvla_loss.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.hvla_loss.restype = C.c_int
-    lib.hvla_train_sizes.argtypes = [vp, i32, C.POINTER(i64)]
+    lib.hvla_train_sizes.argtypes = [vp, i32, i32, C.POINTER(i64)]
     lib.hvla_train_sizes.restype = C.c_int
-    lib.hvla_train_step.argtypes = [vp, C.POINTER(hvla_train_buffers), vp, vp, vp, vp, vp, vp, vp, i32,
+    lib.hvla_train_step.argtypes = [vp, C.POINTER(hvla_train_buffers), vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                     C.POINTER(hvla_train_hyper), vp]
     lib.hvla_train_step.restype = C.c_int
     lib.hvla_train_apply.argtypes = [vp, C.POINTER(hvla_train_buffers), C.POINTER(hvla_train_hyper), vp]
@@ -202,10 +203,11 @@ class Context:
         self._check(self.lib.hvla_loss(self.h, act_ptr, logit_ptr, target_ptr, tmask_ptr, amask_ptr, loss_ptr, B,
                                        C.c_void_p(stream)), "hvla_loss")
 
-    def train_sizes(self, B):
+    def train_sizes(self, B, train_encoder=False):
+        """(n_params, G, workspace_floats, n_hypernet)"""
         out = (C.c_int64 * 4)()
-        self._check(self.lib.hvla_train_sizes(self.h, B, out), "hvla_train_sizes")
-        return int(out[0]), int(out[1]), int(out[2])
+        self._check(self.lib.hvla_train_sizes(self.h, B, int(train_encoder), out), "hvla_train_sizes")
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     def train_step(self, buf, ptrs, B, hyper, stream=0):
         self._check(self.lib.hvla_train_step(self.h, C.byref(buf), *ptrs, B, C.byref(hyper), C.c_void_p(stream)),

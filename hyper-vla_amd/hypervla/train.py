@@ -1,7 +1,8 @@
 """Host side of the fine-tune step (reference: scripts/train.py:405-542 ``train_step_pmap``,
-octo/utils/train_utils.py:295-443 ``create_optimizer``), frozen-image-encoder variant.
+octo/utils/train_utils.py:295-443 ``create_optimizer``).
 
-    ft = FineTuner(model, batch=32)
+    ft = FineTuner(model, batch=32)                         # image encoder frozen (the config default)
+    ft = FineTuner(model, batch=32, train_encoder=True)     # README.md:55 fine_tune_pretrained_image_encoder=True
     loss = ft.step(instruction_dict, initial_state, images, batch)       # fwd + bwd + all-reduce + AdamW + EMA
 
 All arithmetic is in libhvla (csrc/train.hip); torch owns the device buffers and, when a process group is
@@ -14,12 +15,13 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 from . import _native
-from .config import Geometry, generated_leaves
+from .config import Geometry, encoder_leaves, generated_leaves, shared_name
 
 
-def train_param_layout(g: Geometry) -> Tuple[List[Tuple[str, int, Tuple[int, ...]]], int]:
+def train_param_layout(g: Geometry, train_encoder: bool = False) -> Tuple[List[Tuple[str, int, Tuple[int, ...]]], int]:
     """[(name, offset, shape)] of the flat trainable-parameter vector == make_train_layout() in csrc/train.hip.
-    The 73 output heads are the fused entries "W_cat" [C, G] and "b_cat" [G] (columns in pytree leaf order)."""
+    The 73 output heads are the fused entries "W_cat" [C, G] and "b_cat" [G] (columns in pytree leaf order); with
+    `train_encoder` the shared DINOv2 leaves follow as flat vectors under their checkpoint names."""
     C, F = g.ctx_dim, g.ctx_mlp
     out, off = [], 0
 
@@ -46,11 +48,14 @@ def train_param_layout(g: Geometry) -> Tuple[List[Tuple[str, int, Tuple[int, ...
     add("Transformer_0/encoder_norm/scale", (C,)); add("Transformer_0/encoder_norm/bias", (C,))
     G = generated_leaves(g)[-1].offset + generated_leaves(g)[-1].size
     add("W_cat", (C, G)); add("b_cat", (G,))
+    if train_encoder:
+        for path, shape in encoder_leaves(g):
+            add(shared_name(path), (int(np.prod(shape)),))
     return out, off
 
 
-def pack_params(g: Geometry, params: Dict[str, np.ndarray]) -> np.ndarray:
-    layout, total = train_param_layout(g)
+def pack_params(g: Geometry, params: Dict[str, np.ndarray], train_encoder: bool = False) -> np.ndarray:
+    layout, total = train_param_layout(g, train_encoder)
     flat = np.zeros(total, np.float32)
     leaves = generated_leaves(g)
     for name, off, shape in layout:
@@ -65,9 +70,9 @@ def pack_params(g: Geometry, params: Dict[str, np.ndarray]) -> np.ndarray:
     return flat
 
 
-def unpack_params(g: Geometry, flat: np.ndarray) -> Dict[str, np.ndarray]:
+def unpack_params(g: Geometry, flat: np.ndarray, train_encoder: bool = False) -> Dict[str, np.ndarray]:
     """flat vector (parameters or gradients) -> reference-named tensors."""
-    layout, _ = train_param_layout(g)
+    layout, _ = train_param_layout(g, train_encoder)
     leaves = generated_leaves(g)
     out: Dict[str, np.ndarray] = {}
     for name, off, shape in layout:
@@ -93,16 +98,18 @@ def lr_rsqrt(step: int, peak: float, warmup: int = 2000, timescale: int = 10000,
 
 class FineTuner:
     def __init__(self, model, batch: int, peak_lr: float = 3e-4, weight_decay: float = 0.05, clip: float = 1.0,
-                 ema_decay: float = 0.999, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+                 ema_decay: float = 0.999, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8,
+                 train_encoder: bool = False, base_lr: float = None, base_weight_decay: float = 0.0):
         import torch
         self.torch, self.model, self.g, self.B = torch, model, model.geometry, batch
+        self.train_encoder = bool(train_encoder)
         dev = model.device
-        n, G, work = model._ctx.train_sizes(batch)
-        layout, total = train_param_layout(self.g)
+        n, G, work, n_hyper = model._ctx.train_sizes(batch, self.train_encoder)
+        layout, total = train_param_layout(self.g, self.train_encoder)
         assert n == total, (n, total)
-        self.n, self.G = n, G
+        self.n, self.G, self.n_hyper = n, G, n_hyper
         f32 = dict(dtype=torch.float32, device=dev)
-        self.params = torch.as_tensor(pack_params(self.g, model.params)).to(dev)
+        self.params = torch.as_tensor(pack_params(self.g, model.params, self.train_encoder)).to(dev)
         self.grads = torch.zeros(n, **f32)
         self.mu = torch.zeros(n, dtype=torch.bfloat16, device=dev)
         self.nu = torch.zeros(n, **f32)
@@ -114,50 +121,72 @@ class FineTuner:
         self.actions = torch.zeros(batch, self.g.horizon, self.g.action_dim, **f32)
         self.logits = torch.zeros(batch, self.g.horizon, **f32)
         self.sqsum = torch.zeros(1, **f32)
-        mask = np.zeros(G, np.uint8)
+        mask = np.zeros(G + (n - n_hyper), np.uint8)
         for l in generated_leaves(self.g):                     # weight_decay_strategy v5 (train_utils.py:354-363)
             if "kernel" in l.flat_name:
                 mask[l.offset:l.offset + l.size] = 1
+        if self.train_encoder:                                 # base_weight_decay_mask (train_utils.py:414)
+            for name, off, shape in layout:
+                if off >= n_hyper and "kernel" in name:
+                    mask[G + off - n_hyper:G + off - n_hyper + shape[0]] = 1
         self.wd_mask = torch.as_tensor(mask).to(dev)
-        self.buf = _native.hvla_train_buffers(*[t.data_ptr() for t in (
+        # the pull towards the pretrained encoder only exists for base_weight_decay > 0 (scripts/train.py:469)
+        self.params0 = self.params[n_hyper:].clone() if self.train_encoder and base_weight_decay > 0 else None
+        self.buf = _native.hvla_train_buffers(*[t.data_ptr() if t is not None else None for t in (
             self.params, self.grads, self.mu, self.nu, self.ema, self.theta, self.dtheta, self.work, self.loss,
-            self.actions, self.logits, self.sqsum, self.wd_mask)])
-        self.hy = dict(b1=b1, b2=b2, eps=eps, weight_decay=weight_decay, clip=clip, ema_decay=ema_decay)
-        self.peak_lr, self.step_count = peak_lr, 0
+            self.actions, self.logits, self.sqsum, self.wd_mask, self.params0)])
+        self.hy = dict(b1=b1, b2=b2, eps=eps, weight_decay=weight_decay, clip=clip, ema_decay=ema_decay,
+                       base_weight_decay=base_weight_decay)
+        self.peak_lr, self.base_peak_lr, self.step_count = peak_lr, (peak_lr if base_lr is None else base_lr), 0
 
-    def _hyper(self, lr, forward_only=False):
+    def _hyper(self, lr, forward_only=False, base_lr=None):
         h = self.hy
         return _native.hvla_train_hyper(lr, h["b1"], h["b2"], h["eps"], h["weight_decay"], h["clip"], h["ema_decay"],
-                                        self.step_count, int(forward_only))
+                                        self.step_count, int(forward_only), lr if base_lr is None else base_lr,
+                                        h["base_weight_decay"], int(self.train_encoder))
 
-    def forward_backward(self, instruction_dict, initial_state, tokens, batch, forward_only=False):
-        """loss [B] (device) after writing self.grads = d mean(loss) / d params."""
+    def forward_backward(self, instruction_dict, initial_state, tokens_or_images, batch, forward_only=False):
+        """loss [B] (device) after writing self.grads = d mean(loss) / d params.  The fourth argument is the frozen
+        encoder's patch tokens f32 [B, P, E], or -- with train_encoder -- the uint8 observations [B, (1,) H, W, 3]."""
         torch, m, g = self.torch, self.model, self.g
         li = instruction_dict["language_instruction"]
         tok = m._dev(li["token_embedding"], torch.float32)
         msk = m._dev(li["attention_mask"], torch.int64)
         cls = m._dev(np.asarray(initial_state["patch_embeddings"])[:, 0], torch.float32)
-        tkn = m._dev(tokens, torch.float32)
+        if self.train_encoder:
+            img = tokens_or_images
+            if not torch.is_tensor(img):
+                img = np.asarray(img)
+            if img.ndim == 5:
+                img = img[:, 0]
+            obs = m._dev(img, torch.uint8)
+            assert tuple(obs.shape) == (self.B, g.image_size, g.image_size, 3), obs.shape
+            tkn_ptr, img_ptr = None, obs.data_ptr()
+        else:
+            obs = m._dev(tokens_or_images, torch.float32)
+            assert tuple(obs.shape) == (self.B, g.patches, g.enc_dim), obs.shape
+            tkn_ptr, img_ptr = obs.data_ptr(), None
         tgt = m._dev(np.asarray(batch["action"])[:, 0], torch.float32)
         am = m._dev(np.asarray(batch["action_pad_mask"])[:, 0].astype(np.uint8), torch.uint8)
         tm = m._dev(np.asarray(batch["timestep_pad_mask"])[:, 0].astype(np.uint8), torch.uint8)
-        assert tok.shape[0] == self.B and tuple(tkn.shape) == (self.B, g.patches, g.enc_dim)
-        self._keep = (tok, msk, cls, tkn, tgt, am, tm)
-        ptrs = [t.data_ptr() for t in (tok, msk, cls, tkn, tgt, tm, am)]
+        assert tok.shape[0] == self.B
+        self._keep = (tok, msk, cls, obs, tgt, am, tm)
+        ptrs = [tok.data_ptr(), msk.data_ptr(), cls.data_ptr(), tkn_ptr, img_ptr, tgt.data_ptr(), tm.data_ptr(), am.data_ptr()]
         m._ctx.train_step(self.buf, ptrs, self.B, self._hyper(0.0, forward_only), m._stream())
         return self.loss
 
-    def apply(self, lr=None):
+    def apply(self, lr=None, base_lr=None):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.grads)                               # RCCL; pmean(grads) of scripts/train.py:460
             self.grads /= dist.get_world_size()
         lr = lr_rsqrt(self.step_count, self.peak_lr) if lr is None else lr
-        self.model._ctx.train_apply(self.buf, self._hyper(lr), self.model._stream())
+        base_lr = lr_rsqrt(self.step_count, self.base_peak_lr) if base_lr is None else base_lr
+        self.model._ctx.train_apply(self.buf, self._hyper(lr, base_lr=base_lr), self.model._stream())
         self.step_count += 1
 
-    def step(self, instruction_dict, initial_state, images, batch, lr=None):
-        tokens = self.model.encode_images(images)                     # frozen encoder
-        loss = self.forward_backward(instruction_dict, initial_state, tokens, batch)
-        self.apply(lr)
+    def step(self, instruction_dict, initial_state, images, batch, lr=None, base_lr=None):
+        obs = images if self.train_encoder else self.model.encode_images(images)
+        loss = self.forward_backward(instruction_dict, initial_state, obs, batch)
+        self.apply(lr, base_lr)
         return loss.mean()

@@ -133,7 +133,8 @@ int hvla_loss(hvla_ctx* ctx, const float* actions, const float* gripper_logits, 
  * frozen T5 / initial-image encoders that feed it; octo/utils/train_utils.py:295-443 `create_optimizer`):
  * forward + backward of mean_b MixLoss(policy(theta_b(params), tokens_b), action_b), then (hvla_train_apply)
  * clip-by-global-norm -> AdamW with bf16 first moment and the v5 weight-decay mask -> EMA.  The image encoder is
- * frozen in this version (`fine_tune_pretrained_image_encoder=False`): `tokens` come from hvla_encode.  Between the
+ * either frozen (`fine_tune_pretrained_image_encoder=False`, the config default: `tokens` come from hvla_encode) or
+ * trained (README.md:55; its leaves form the "shared" optimizer group at base_lr / base_weight_decay).  Between the
  * two calls the caller all-reduces `grads` over ranks (RCCL; scripts/train.py:460 `pmean`).
  * Every buffer is DEVICE memory owned by the caller; the flat parameter order is make_train_layout()
  * (csrc/train.hip) == hypervla.train.train_param_layout(); sizes from hvla_train_sizes.                  */
@@ -150,17 +151,25 @@ typedef struct hvla_train_buffers {
   float* actions;          /* [B, horizon, action_dim] or NULL                                */
   float* logits;           /* [B, horizon] or NULL                                            */
   float* sqsum;            /* [1] scratch for the global gradient norm                        */
-  const uint8_t* wd_mask;  /* [G] 1 where the generated leaf is a base-net kernel (v5 mask)   */
+  const uint8_t* wd_mask;  /* [G] 1 where the generated leaf is a base-net kernel (v5 mask);  */
+                           /*   + [n_encoder] 1 on shared "kernel" leaves when train_encoder   */
+  const float* params0;    /* [n_encoder] pretrained encoder weights (delta decay) or NULL     */
 } hvla_train_buffers;
 typedef struct hvla_train_hyper {
   float lr, b1, b2, eps, weight_decay, clip, ema_decay;
   int32_t step, forward_only;
+  float base_lr, base_weight_decay; /* optimizer group of the shared DINOv2 leaves               */
+  int32_t train_encoder;            /* base_vit.py:67 fine_tune_pretrained_image_encoder        */
 } hvla_train_hyper;
-int hvla_train_sizes(hvla_ctx* ctx, int32_t B, int64_t out[4]); /* n_params, G, workspace_floats, 0 */
+/* out = { n_params, G, workspace_floats, n_hypernet }.  With train_encoder the shared DINOv2 leaves
+ * (hypervla.config.encoder_leaves order) occupy params[n_hypernet, n_params).                     */
+int hvla_train_sizes(hvla_ctx* ctx, int32_t B, int32_t train_encoder, int64_t out[4]);
+/* Exactly one of `tokens` (f32 [B, P, E] from hvla_encode: frozen encoder) and `images` (u8 [B, H, W, 3]:
+ * DINOv2 runs in f32 inside the step and receives gradients, README.md:55) is non-NULL.          */
 int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* token_embedding,
                     const int64_t* attention_mask, const float* initial_cls, const float* tokens,
-                    const float* target, const uint8_t* timestep_mask, const uint8_t* action_mask, int32_t B,
-                    const hvla_train_hyper* hyper, void* stream);
+                    const uint8_t* images, const float* target, const uint8_t* timestep_mask,
+                    const uint8_t* action_mask, int32_t B, const hvla_train_hyper* hyper, void* stream);
 int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_train_hyper* hyper, void* stream);
 
 /* Live per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).

@@ -246,10 +246,13 @@ def mix_loss(g, cont, logits, actions, timestep_pad_mask, action_pad_mask, clip_
     return per, per.mean()
 
 
-def train_loss_and_grads(params, g, leaves, instruction_dict, initial_state, tokens, batch, dtype=torch.float64):
-    """Loss and d(loss)/d(HN params) with the image encoder frozen (tokens given): autograd through
-    hypernetwork -> generated theta -> per-sample policy -> mix loss.  This is the gradient oracle for the
-    fine-tune step."""
+def train_loss_and_grads(params, g, leaves, instruction_dict, initial_state, tokens, batch, dtype=torch.float64,
+                         images=None, enc_shapes=None):
+    """Loss and d(loss)/d(HN params): autograd through hypernetwork -> generated theta -> per-sample policy -> mix
+    loss.  With `images` (and `enc_shapes`) the DINOv2 encoder is part of the graph
+    (base_vit.py:128 `fine_tune_pretrained_image_encoder=True`) and the returned dict also holds the gradient of every
+    shared `encoder_image_encoder_*` leaf as a flat vector in the checkpoint's (flax) layout; otherwise the encoder is
+    frozen and `tokens` are given.  This is the gradient oracle for the fine-tune step."""
     hn = HyperNetRef(params, g, leaves, dtype)
     names = sorted(hn.p)
     for k in names:
@@ -259,7 +262,58 @@ def train_loss_and_grads(params, g, leaves, instruction_dict, initial_state, tok
     li = instruction_dict["language_instruction"]
     ctx = hn.context(li["token_embedding"], li["attention_mask"], np.asarray(initial_state["patch_embeddings"])[:, 0])
     theta = hn.generate(ctx)
-    act, logit, _ = PolicyRef(g, leaves)(theta, torch.as_tensor(np.asarray(tokens)).to(dtype))
+    enc = None
+    if images is not None:
+        enc = build_hf_dinov2(params, g, enc_shapes, dtype).train(False)
+        for q in enc.parameters():
+            q.requires_grad_(True)
+        x = torch.as_tensor(np.asarray(images)).to(dtype)
+        if x.ndim == 5:
+            x = x[:, 0]
+        x = (x / 255.0 - _MEAN.to(dtype)) / _STD.to(dtype)
+        tok_t = enc(pixel_values=x.permute(0, 3, 1, 2).contiguous()).last_hidden_state[:, 1:]
+    else:
+        tok_t = torch.as_tensor(np.asarray(tokens)).to(dtype)
+    act, logit, _ = PolicyRef(g, leaves)(theta, tok_t)
     per, loss = mix_loss(g, act[..., :-1], logit, batch["action"], batch["timestep_pad_mask"], batch["action_pad_mask"])
-    grads = torch.autograd.grad(loss, [hn.p[k] for k in names], allow_unused=True)
-    return per.detach(), loss.detach(), {k: (gr.detach() if gr is not None else torch.zeros_like(hn.p[k])) for k, gr in zip(names, grads)}
+    wrt = [hn.p[k] for k in names]
+    enc_named = list(enc.named_parameters()) if enc is not None else []
+    grads = torch.autograd.grad(loss, wrt + [q for _, q in enc_named], allow_unused=True)
+    out = {k: (gr.detach() if gr is not None else torch.zeros_like(hn.p[k])) for k, gr in zip(names, grads)}
+    if enc is not None:
+        hf = {n: (gr.detach() if gr is not None else torch.zeros_like(q)) for (n, q), gr in zip(enc_named, grads[len(wrt):])}
+        out.update(_hf_grads_to_flax(hf, g))
+    return per.detach(), loss.detach(), out
+
+
+def _hf_grads_to_flax(hf, g):
+    """torch Dinov2Model parameter names / layouts -> the checkpoint's flat `encoder_image_encoder_*` vectors
+    (inverse of build_hf_dinov2: Linear weights transposed back to [in, out], conv OIHW -> HWIO)."""
+    pre, out = "encoder_image_encoder_", {}
+
+    def put(path, t):
+        out[pre + "_".join(path)] = t.contiguous().reshape(-1)
+
+    put(("embeddings", "cls_token"), hf["embeddings.cls_token"])
+    put(("embeddings", "mask_token"), hf["embeddings.mask_token"])
+    put(("embeddings", "position_embeddings"), hf["embeddings.position_embeddings"])
+    put(("embeddings", "patch_embeddings", "projection", "kernel"), hf["embeddings.patch_embeddings.projection.weight"].permute(2, 3, 1, 0))
+    put(("embeddings", "patch_embeddings", "projection", "bias"), hf["embeddings.patch_embeddings.projection.bias"])
+    for i in range(g.enc_layers):
+        L, T = ("encoder", "layer", str(i)), f"encoder.layer.{i}."
+        for nm in ("norm1", "norm2"):
+            put(L + (nm, "scale"), hf[T + nm + ".weight"])
+            put(L + (nm, "bias"), hf[T + nm + ".bias"])
+        for nm in ("query", "key", "value"):
+            put(L + ("attention", "attention", nm, "kernel"), hf[T + f"attention.attention.{nm}.weight"].t())
+            put(L + ("attention", "attention", nm, "bias"), hf[T + f"attention.attention.{nm}.bias"])
+        put(L + ("attention", "output", "dense", "kernel"), hf[T + "attention.output.dense.weight"].t())
+        put(L + ("attention", "output", "dense", "bias"), hf[T + "attention.output.dense.bias"])
+        put(L + ("layer_scale1", "lambda1"), hf[T + "layer_scale1.lambda1"])
+        put(L + ("layer_scale2", "lambda1"), hf[T + "layer_scale2.lambda1"])
+        for fc in ("fc1", "fc2"):
+            put(L + ("mlp", fc, "kernel"), hf[T + f"mlp.{fc}.weight"].t())
+            put(L + ("mlp", fc, "bias"), hf[T + f"mlp.{fc}.bias"])
+    put(("layernorm", "scale"), hf["layernorm.weight"])
+    put(("layernorm", "bias"), hf["layernorm.bias"])
+    return out

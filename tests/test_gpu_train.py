@@ -1,4 +1,4 @@
-"""GPU: fine-tune step (A13, frozen image encoder) through the C ABI against the autograd gradient oracle."""
+"""GPU: fine-tune step (A13; frozen and trained image encoder) through the C ABI against the autograd gradient oracle."""
 import numpy as np
 import pytest
 
@@ -126,3 +126,100 @@ def test_full_geometry_gradients(golden_dir):
     worst = max((np.abs(got[k].reshape(v.shape) - v.numpy()).max() / max(float(v.abs().max()), 1e-4 * gmax), k) for k, v in grads.items())
     print("full geometry worst relative gradient error", worst)
     assert worst[0] <= 3e-3, worst
+
+
+# ------------------------------------------------------------------ trained image encoder (README.md:55)
+def _encoder_case(g, B, tol, seed_rank=0):
+    from hypervla import synthetic as syn
+    from hypervla.config import encoder_leaves, generated_leaves
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner, unpack_params
+    from oracle import hvla_ref_torch as ot
+    model = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st, im = syn.synthetic_instructions(B, g, seed_rank), syn.synthetic_initial_state(B, g, seed_rank), syn.synthetic_images(B, g, seed_rank)
+    batch = syn.synthetic_action_batch(B, g, seed_rank)
+    per, loss, grads = ot.train_loss_and_grads(model.params, g, generated_leaves(g), ins, st, None, batch, images=im,
+                                               enc_shapes=dict(encoder_leaves(g)))
+    ft = FineTuner(model, B, train_encoder=True)
+    got_loss = ft.forward_backward(ins, st, im, batch).cpu().numpy()
+    np.testing.assert_allclose(got_loss, per.numpy(), rtol=3e-4, atol=3e-5)
+    got = unpack_params(g, ft.grads.cpu().numpy(), train_encoder=True)
+    assert set(got) == set(grads), set(got) ^ set(grads)
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    rel = sorted(((np.abs(got[k].reshape(v.shape) - v.numpy()).max() / max(float(v.abs().max()), 1e-4 * gmax), k)
+                  for k, v in grads.items()), reverse=True)
+    print("worst relative gradient errors (trained encoder):", [(f"{r:.2e}", k) for r, k in rel[:6]])
+    enc_rel = [r for r in rel if r[1].startswith("encoder_image_encoder_")]
+    assert len(enc_rel) == len(encoder_leaves(g))
+    assert any(float(grads[k].abs().max()) > 0 for _, k in enc_rel)
+    assert rel[0][0] <= tol, rel[:6]
+    return model, ft, (ins, st, im, batch)
+
+
+def test_encoder_gradients_match_autograd():
+    """Every DINOv2 leaf (patch conv, cls / position embeddings, LayerScale, 12x attention + MLP, final LayerNorm) and
+    every hypernetwork leaf against float64 autograd through transformers' Dinov2Model + the restated policy."""
+    from hypervla.config import MID
+    _encoder_case(MID, 3, 2e-3)
+
+
+@pytest.mark.timeout(1200)
+def test_encoder_gradients_full_geometry():
+    from hypervla.config import FULL
+    _encoder_case(FULL, 1, 3e-3)
+
+
+def test_two_group_optimizer_and_delta_decay():
+    """multi_transform{generated: AdamW(lr, v5 mask), shared: AdamW(base_lr, kernel mask)} under one global-norm clip,
+    plus the pull towards the pretrained encoder (train_utils.py:411-426, scripts/train.py:465-471)."""
+    from hypervla import synthetic as syn
+    from hypervla.config import MID, generated_leaves
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner, train_param_layout
+    g, B = MID, 2
+    model = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    batch = syn.synthetic_action_batch(B, g)
+    wd, bwd, lr, blr, b1, b2, eps = 0.05, 0.01, 1e-3, 2e-4, 0.9, 0.999, 1e-8
+    ft = FineTuner(model, B, weight_decay=wd, train_encoder=True, base_weight_decay=bwd)
+    ft.params[ft.n_hyper:] += 0.01 * torch.randn_like(ft.params[ft.n_hyper:])      # move away from the pretrained point
+    ft.forward_backward(ins, st, im, batch)
+    p0 = ft.params.cpu().numpy().astype(np.float64)
+    pre = ft.params0.cpu().numpy().astype(np.float64)
+    gr = ft.grads.cpu().numpy().astype(np.float64)
+    ft.apply(lr=lr, base_lr=blr)
+    gc = gr * min(1.0, 1.0 / np.sqrt((gr * gr).sum()))
+    upd = ((1 - b1) * gc / (1 - b1)) / (np.sqrt((1 - b2) * gc * gc / (1 - b2)) + eps)
+    layout, total = train_param_layout(g, True)
+    nh, G = ft.n_hyper, ft.G
+    cols = np.zeros(G, bool)
+    for l in generated_leaves(g):
+        if "kernel" in l.flat_name:
+            cols[l.offset:l.offset + l.size] = True
+    want = p0.copy()
+    for name, off, shape in layout:
+        n = int(np.prod(shape))
+        sl = slice(off, off + n)
+        if off < nh:
+            m = np.tile(cols, shape[0]) if name == "W_cat" else cols if name == "b_cat" else np.zeros(n, bool)
+            want[sl] = p0[sl] - lr * (upd[sl] + wd * p0[sl] * m)
+        else:
+            k = 1.0 if "kernel" in name else 0.0
+            want[sl] = p0[sl] - blr * (upd[sl] + bwd * k * p0[sl] - bwd * pre[off - nh:off - nh + n])
+    np.testing.assert_allclose(ft.params.cpu().numpy(), want, rtol=0, atol=2e-6)
+
+
+def test_encoder_training_reduces_loss():
+    from hypervla.config import MID
+    from hypervla import synthetic as syn
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner
+    g, B = MID, 4
+    model = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    batch = syn.synthetic_action_batch(B, g)
+    ft = FineTuner(model, B, train_encoder=True)
+    before = ft.params[ft.n_hyper:].clone()
+    losses = [float(ft.step(ins, st, im, batch, lr=1e-3, base_lr=1e-4)) for _ in range(8)]
+    assert losses[-1] < losses[0], losses
+    assert float((ft.params[ft.n_hyper:] - before).abs().max()) > 0      # the encoder really moved
