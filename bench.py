@@ -80,7 +80,7 @@ def finetune_bench(a, model, rank, world, use_dist):
     from hypervla.train import FineTuner
     import torch.distributed as dist
     g, B, dev = model.geometry, a.batch, model.device
-    ft = FineTuner(model, B)
+    ft = FineTuner(model, B, train_encoder=a.train_encoder)
     ins, st = syn.synthetic_instructions(B, g, rank), syn.synthetic_initial_state(B, g, rank)
     images = torch.as_tensor(syn.synthetic_images(B, g, rank)[:, 0]).to(dev).contiguous()
     batch = syn.synthetic_action_batch(B, g, rank)
@@ -102,11 +102,15 @@ def finetune_bench(a, model, rank, world, use_dist):
             "metric": "finetune_samples_per_sec", "value": round(whole_job_rate(B, world, a.steps, elapsed), 2),
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (policy/hypernet fwd+bwd) + " + a.enc_dtype + " (frozen encoder)",
+            "vs_baseline": None,
+            "dtype": "f32" if a.train_encoder else "f32 (policy/hypernet fwd+bwd) + " + a.enc_dtype + " (frozen encoder)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4] variant: fine-tune step with the image encoder frozen "
-                                   "(encode + fwd + bwd + grad all-reduce + clip/AdamW(bf16 mu)/EMA), hypernetwork "
-                                   "parameters only", "batch_per_gpu": B, "global_batch": B * world,
+            "config": {"workload": ("BASELINE configs[4]: fine-tune step, DINOv2 encoder trained (README.md:55): "
+                                    "fwd + bwd through encoder, policy and hypernetwork + grad all-reduce + "
+                                    "clip/AdamW(bf16 mu, two groups)/EMA") if a.train_encoder else
+                                   ("BASELINE configs[4] variant: fine-tune step with the image encoder frozen "
+                                    "(encode + fwd + bwd + grad all-reduce + clip/AdamW(bf16 mu)/EMA), hypernetwork "
+                                    "parameters only"), "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}, RCCL all-reduce of {ft.n} f32 gradients"},
             "loss_first": round(losses[0], 5) if losses else None, "loss_last": round(float(last), 5)}))
     if use_dist:
@@ -123,7 +127,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (BASELINE config 3)")
     ap.add_argument("--finetune", action="store_true",
-                    help="BASELINE config 5 (frozen-encoder variant): encode + fwd + bwd + RCCL grad all-reduce + AdamW + EMA")
+                    help="BASELINE config 5: encode + fwd + bwd + RCCL grad all-reduce + AdamW + EMA (encoder frozen "
+                         "unless --train-encoder)")
+    ap.add_argument("--train-encoder", action="store_true",
+                    help="with --finetune: fine_tune_pretrained_image_encoder=True (README.md:55)")
     a = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))

@@ -36,6 +36,7 @@ struct BG {
   int nb1;                    // batch = blockIdx.z = b0 * nb1 + b1
   float alpha;
   int accumulate;             // 0 store, 1 C += (one writer per element), 2 atomic C += (batches share C)
+  int ksplit = 1;             // > 1: K is cut into ksplit chunks over blockIdx.z, reduced with atomics (accumulate != 0)
 };
 
 // 64x64 output tile per workgroup, 4 waves x (32x32) on the exact-f32 matrix instruction
@@ -45,7 +46,10 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
   __shared__ float As[16][64];
   __shared__ float Bs[16][64];
-  const int b0 = blockIdx.z / g.nb1, b1 = blockIdx.z % g.nb1;
+  const int zb = blockIdx.z / g.ksplit, kc = blockIdx.z % g.ksplit;
+  const int b0 = zb / g.nb1, b1 = zb % g.nb1;
+  const int kchunk = ((g.K + g.ksplit - 1) / g.ksplit + 15) & ~15;
+  const int kbeg = kc * kchunk, kend = kbeg + kchunk < g.K ? kbeg + kchunk : g.K;
   const float* A = g.A + b0 * g.sA0 + b1 * g.sA1;
   const float* B = g.B + b0 * g.sB0 + b1 * g.sB1;
   float* C = g.C + b0 * g.sC0 + b1 * g.sC1;
@@ -55,13 +59,13 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < g.K; k0 += 16) {
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
       int mm, kk;
       if (TA) { mm = i & 63; kk = i >> 6; } else { kk = i & 15; mm = i >> 4; }
       const int m = m0 + mm, k = k0 + kk;
       float v = 0.f;
-      if (m < g.M && k < g.K) v = TA ? A[(long)k * g.lda + m] : A[(long)m * g.lda + k];
+      if (m < g.M && k < kend) v = TA ? A[(long)k * g.lda + m] : A[(long)m * g.lda + k];
       As[kk][mm] = v;
     }
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
       if (TB) { kk = i & 15; nn = i >> 4; } else { nn = i & 63; kk = i >> 6; }
       const int n = n0 + nn, k = k0 + kk;
       float v = 0.f;
-      if (n < g.N && k < g.K) v = TB ? B[(long)n * g.ldb + k] : B[(long)k * g.ldb + n];
+      if (n < g.N && k < kend) v = TB ? B[(long)n * g.ldb + k] : B[(long)k * g.ldb + n];
       Bs[kk][nn] = v;
     }
     __syncthreads();
@@ -81,20 +85,28 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
   const float* bias = g.bias ? g.bias + b0 * g.sBias0 : nullptr;
   const int n = n0 + wn * 32 + col;
   if (n >= g.N) return;
-  const float bn = bias ? bias[n] : 0.f;
+  const float bn = bias && kc == 0 ? bias[n] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + crow(r, half);
     if (m >= g.M) continue;
     const float v = g.alpha * acc[r] + bn;
     float* c = C + (long)m * g.ldc + n;
-    if (g.accumulate == 2) unsafeAtomicAdd(c, v);          // several batches reduce into one C
+    if (g.accumulate == 2 || g.ksplit > 1) unsafeAtomicAdd(c, v);          // several batches reduce into one C
     else *c = g.accumulate ? *c + v : v;
   }
 }
 
-static void bgemm(hipStream_t st, bool ta, bool tb, const BG& g, int nb0) {
-  dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, nb0 * g.nb1);
+static void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
+  // deep-K products onto few output tiles (shared-weight gradients: K = all rows of the batch) would leave most CUs
+  // idle: cut K so that the grid has >= ~1024 workgroups; legal whenever the result is accumulated (C zeroed before)
+  const long tiles = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * nb0 * g.nb1;
+  if (g.accumulate != 0 && g.ksplit == 1 && tiles < 1024 && g.K >= 256) {
+    long ks = (1024 + tiles - 1) / tiles, kmax = g.K / 128;
+    g.ksplit = (int)(ks < kmax ? ks : kmax);
+    if (g.ksplit < 1) g.ksplit = 1;
+  }
+  dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, nb0 * g.nb1 * g.ksplit);
   if (!ta && !tb) hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, dim3(256), 0, st, g);
   else if (!ta && tb) hipLaunchKernelGGL((bgemm_kernel<false, true>), grid, dim3(256), 0, st, g);
   else if (ta && !tb) hipLaunchKernelGGL((bgemm_kernel<true, false>), grid, dim3(256), 0, st, g);
