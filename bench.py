@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="episodes per GPU")
     ap.add_argument("--enc-dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--encoder", default="base", choices=["base", "small"],
+                    help="DINOv2-base (README / reference parity, default) or DINOv2-small (E=384, BASELINE configs[1] wording)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (BASELINE config 3)")
     ap.add_argument("--finetune", action="store_true",
@@ -144,10 +146,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # RCCL; used only for barrier + max(time)
 
     from hypervla import synthetic as syn
-    from hypervla.config import FULL
+    from hypervla.config import FULL, SMALL_E
     from hypervla.dp import max_over_ranks, whole_job_rate
     from hypervla.model import HyperVLA
-    g, B = FULL, a.batch
+    g, B = (SMALL_E if a.encoder == "small" else FULL), a.batch
     model = HyperVLA.from_synthetic(g, device=local, max_batch=B, enc_dtype=a.enc_dtype)
     dev = model.device
     if a.finetune:
@@ -245,7 +247,7 @@ def main():
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_pmc_{nm}_size_by_kernel.csv"))):
                 if "gemm256r_kernel<hvla::OpF16, 2" in row["kernel"]:
                     vals[nm] = float(row["mean"]) * 1024.0
-        if B == 256 and a.enc_dtype == "f16" and len(vals) == 2:
+        if B == 256 and a.enc_dtype == "f16" and a.encoder == "base" and len(vals) == 2:
             traffic = int(2 * vals["fetch"] + vals["write"])
     except Exception:
         traffic = None
@@ -258,14 +260,14 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.enc_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: hypernet weight-gen once (untimed) + full sample_actions step "
-                               "(u8 224x224 -> DINOv2-base E=768 in the loop -> generated vit_t 4L/64d policy -> "
+                               f"(u8 224x224 -> DINOv2-{a.encoder} E={g.enc_dim} in the loop -> generated vit_t 4L/64d policy -> "
                                "[4,7] action chunk); 1 action = 1 sample-step",
-                   "batch_per_gpu": B, "global_batch": world * B, "encoder": "DINOv2-base (reference parity, E=768)",
+                   "batch_per_gpu": B, "global_batch": world * B, "encoder": "DINOv2-base (reference parity, E=768)" if a.encoder == "base" else "DINOv2-small (E=384)",
                    "parallelism": f"episode-dp{world} (no collectives)",
                    "encoder_operands": a.enc_dtype, "policy_operands": "split-bf16 (bf16x3)",
                    "launch": "hipGraph replay" if a.graph else "eager (about 95 launches per step)"},
         "p50_step_latency_ms": round(float(np.median(lat)), 4),
-        "roofline": {"bound": "mfma", "kernel": "gemm256r_kernel<Op,EPI_GELU> (encoder fc1: [B*257,768]x[768,3072] + bias + erf-GELU)",
+        "roofline": {"bound": "mfma", "kernel": f"gemm256r_kernel<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",
                      "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_unit": "bytes/launch (HBM-side, PMC: 2*FETCH_SIZE+WRITE_SIZE; algorithmic 510 MB)",

@@ -13,7 +13,10 @@
 // recomputed in the backward pass.  Parity: every gradient leaf against autograd on the float64 CPU
 // restatement (tests/test_gpu_train.py).
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -97,16 +100,163 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix cores at f32-class accuracy: every f32 operand element is split while it is
+// staged into LDS, x = hi + lo (two bf16, 16 mantissa bits together), and each 16-deep k chunk costs three
+// v_mfma_f32_32x32x16_bf16 (lo*hi + hi*lo + hi*hi; the dropped lo*lo term is 2^-16 relative) -- about 5x the f32
+// instruction's rate.  Both operands are staged k-contiguous ([row][k], 80-byte rows: conflict-free ds_read_b128
+// fragments) whatever their layout in memory; a transposed source is read along its contiguous dimension and turned
+// while it is written.  4 waves as 2 x 2, BM x BN in {128 x 128, 64 x 64}, register-prefetched k steps of 32.
+// ------------------------------------------------------------------------------------------------
+template <bool T, int BR>
+__device__ __forceinline__ void stage_load(const float* __restrict__ P, int ld, int r0, int R, int k0, int kend, bool vec,
+                                           float4 (&out)[BR * 8 / 256]) {
+#pragma unroll
+  for (int j = 0; j < BR * 8 / 256; ++j) {
+    const int idx = threadIdx.x + j * 256;
+    const int row = T ? idx % BR : idx >> 3, kq = T ? (idx / BR) * 4 : (idx & 7) * 4;
+    const int r = r0 + row, k = k0 + kq;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < R && k < kend) {
+      if (!T) {
+        const float* p = P + (long)r * ld + k;
+        if (vec && k + 3 < kend) v = *reinterpret_cast<const float4*>(p);
+        else { v.x = p[0]; if (k + 1 < kend) v.y = p[1]; if (k + 2 < kend) v.z = p[2]; if (k + 3 < kend) v.w = p[3]; }
+      } else {
+        const float* p = P + (long)k * ld + r;
+        v.x = p[0]; if (k + 1 < kend) v.y = p[ld]; if (k + 2 < kend) v.z = p[2 * (long)ld]; if (k + 3 < kend) v.w = p[3 * (long)ld];
+      }
+    }
+    out[j] = v;
+  }
+}
+template <bool T, int BR>
+__device__ __forceinline__ void stage_store(__bf16* __restrict__ hi, __bf16* __restrict__ lo, const float4 (&in)[BR * 8 / 256]) {
+#pragma unroll
+  for (int j = 0; j < BR * 8 / 256; ++j) {
+    const int idx = threadIdx.x + j * 256;
+    const int row = T ? idx % BR : idx >> 3, kq = T ? (idx / BR) * 4 : (idx & 7) * 4;
+    bf16x4 h, l;
+    __bf16 a, b;
+    split1(in[j].x, a, b); h[0] = a; l[0] = b;
+    split1(in[j].y, a, b); h[1] = a; l[1] = b;
+    split1(in[j].z, a, b); h[2] = a; l[2] = b;
+    split1(in[j].w, a, b); h[3] = a; l[3] = b;
+    *reinterpret_cast<bf16x4*>(hi + row * 40 + kq) = h;
+    *reinterpret_cast<bf16x4*>(lo + row * 40 + kq) = l;
+  }
+}
+
+template <bool TA, bool TB, int BM, int BN>
+__global__ __launch_bounds__(256) void bgemm3_kernel(BG g, int vecA, int vecB) {
+  constexpr int LD = 40, WM = BM / 2, WN = BN / 2, IM = WM / 32, IN = WN / 32;
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[BM * LD], Al[BM * LD], Bh[BN * LD], Bl[BN * LD];
+  const int zb = blockIdx.z / g.ksplit, kc = blockIdx.z % g.ksplit;
+  const int b0 = zb / g.nb1, b1 = zb % g.nb1;
+  const int kchunk = ((g.K + g.ksplit - 1) / g.ksplit + 31) & ~31;
+  const int kbeg = kc * kchunk, kend = kbeg + kchunk < g.K ? kbeg + kchunk : g.K;
+  const float* A = g.A + b0 * g.sA0 + b1 * g.sA1;
+  const float* B = g.B + b0 * g.sB0 + b1 * g.sB1;
+  float* C = g.C + b0 * g.sC0 + b1 * g.sC1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1, col = lane & 31, half = lane >> 5;
+  f32x16 acc[IM][IN];
+#pragma unroll
+  for (int a = 0; a < IM; ++a)
+#pragma unroll
+    for (int b = 0; b < IN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float4 ra[BM * 8 / 256], rb[BN * 8 / 256];
+  if (kbeg < kend) {
+    stage_load<TA, BM>(A, g.lda, m0, g.M, kbeg, kend, vecA != 0, ra);
+    stage_load<!TB, BN>(B, g.ldb, n0, g.N, kbeg, kend, vecB != 0, rb);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    __syncthreads();                                     // the previous step's fragment reads are done
+    stage_store<TA, BM>(Ah, Al, ra);
+    stage_store<!TB, BN>(Bh, Bl, rb);
+    __syncthreads();
+    if (k0 + 32 < kend) {                                // next step's global loads fly under this step's MFMAs
+      stage_load<TA, BM>(A, g.lda, m0, g.M, k0 + 32, kend, vecA != 0, ra);
+      stage_load<!TB, BN>(B, g.ldb, n0, g.N, k0 + 32, kend, vecB != 0, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 16) {
+      Split8 fa[IM], fb[IN];
+#pragma unroll
+      for (int a = 0; a < IM; ++a) {
+        const int o = (wm * WM + a * 32 + col) * LD + kk + half * 8;
+        fa[a].hi = *reinterpret_cast<const bf16x8*>(Ah + o);
+        fa[a].lo = *reinterpret_cast<const bf16x8*>(Al + o);
+      }
+#pragma unroll
+      for (int b = 0; b < IN; ++b) {
+        const int o = (wn * WN + b * 32 + col) * LD + kk + half * 8;
+        fb[b].hi = *reinterpret_cast<const bf16x8*>(Bh + o);
+        fb[b].lo = *reinterpret_cast<const bf16x8*>(Bl + o);
+      }
+#pragma unroll
+      for (int a = 0; a < IM; ++a)
+#pragma unroll
+        for (int b = 0; b < IN; ++b) acc[a][b] = mma32_x3(fa[a], fb[b], acc[a][b]);
+    }
+  }
+  const float* bias = g.bias && kc == 0 ? g.bias + b0 * g.sBias0 : nullptr;
+#pragma unroll
+  for (int b = 0; b < IN; ++b) {
+    const int n = n0 + wn * WN + b * 32 + col;
+    if (n >= g.N) continue;
+    const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < IM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + a * 32 + crow(r, half);
+        if (m >= g.M) continue;
+        const float v = g.alpha * acc[a][b][r] + bn;
+        float* c = C + (long)m * g.ldc + n;
+        if (g.accumulate == 2 || g.ksplit > 1) unsafeAtomicAdd(c, v);
+        else *c = g.accumulate ? *c + v : v;
+      }
+  }
+}
+
+template <int BM, int BN>
+static void launch_bgemm3(hipStream_t st, bool ta, bool tb, const BG& g, dim3 grid, int va, int vb) {
+  if (!ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<false, false, BM, BN>), grid, dim3(256), 0, st, g, va, vb);
+  else if (!ta && tb) hipLaunchKernelGGL((bgemm3_kernel<false, true, BM, BN>), grid, dim3(256), 0, st, g, va, vb);
+  else if (ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<true, false, BM, BN>), grid, dim3(256), 0, st, g, va, vb);
+  else hipLaunchKernelGGL((bgemm3_kernel<true, true, BM, BN>), grid, dim3(256), 0, st, g, va, vb);
+}
+
+// HVLA_TRAIN_GEMM=f32 selects the exact-f32 matrix instruction (bitwise fmaf chains) instead of the split-bf16 path
+static bool train_gemm_exact() {
+  static const int v = [] { const char* e = getenv("HVLA_TRAIN_GEMM"); return e && !strcmp(e, "f32") ? 1 : 0; }();
+  return v != 0;
+}
+
 static void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
+  const bool exact = train_gemm_exact();
+  const int T = !exact && g.M >= 96 && g.N >= 96 ? 128 : 64;
   // deep-K products onto few output tiles (shared-weight gradients: K = all rows of the batch) would leave most CUs
   // idle: cut K so that the grid has >= ~1024 workgroups; legal whenever the result is accumulated (C zeroed before)
-  const long tiles = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * nb0 * g.nb1;
+  const long tiles = (long)((g.N + T - 1) / T) * ((g.M + T - 1) / T) * nb0 * g.nb1;
   if (g.accumulate != 0 && g.ksplit == 1 && tiles < 1024 && g.K >= 256) {
     long ks = (1024 + tiles - 1) / tiles, kmax = g.K / 128;
     g.ksplit = (int)(ks < kmax ? ks : kmax);
     if (g.ksplit < 1) g.ksplit = 1;
   }
-  dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, nb0 * g.nb1 * g.ksplit);
+  dim3 grid((g.N + T - 1) / T, (g.M + T - 1) / T, nb0 * g.nb1 * g.ksplit);
+  if (!exact) {
+    // float4 staging needs 16-byte aligned rows of the k-contiguous operands
+    auto al = [](const float* p, int ld, long s0, long s1) { return ((uintptr_t)p % 16 == 0) && ld % 4 == 0 && s0 % 4 == 0 && s1 % 4 == 0; };
+    const int va = !ta && al(g.A, g.lda, g.sA0, g.sA1), vb = tb && al(g.B, g.ldb, g.sB0, g.sB1);
+    if (T == 128) launch_bgemm3<128, 128>(st, ta, tb, g, grid, va, vb);
+    else launch_bgemm3<64, 64>(st, ta, tb, g, grid, va, vb);
+    return;
+  }
   if (!ta && !tb) hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, dim3(256), 0, st, g);
   else if (!ta && tb) hipLaunchKernelGGL((bgemm_kernel<false, true>), grid, dim3(256), 0, st, g);
   else if (ta && !tb) hipLaunchKernelGGL((bgemm_kernel<true, false>), grid, dim3(256), 0, st, g);
@@ -465,19 +615,6 @@ __global__ void ctx_final_bwd_kernel(const float* __restrict__ x, long xstride, 
     unsafeAtomicAdd(dscale + c, dy * xh);
     unsafeAtomicAdd(dbias + c, dy);
   }
-}
-
-// dctx[b][c] += sum_g dtheta[b][g] W[c][g] over a chunk of g (split-K with atomics)
-__global__ void dctx_kernel(const float* __restrict__ dth, const float* __restrict__ W, float* __restrict__ dctx, int B,
-                            int C, long G, int chunk) {
-  const int b = blockIdx.y, c = threadIdx.x >> 6, lane = threadIdx.x & 63;      // 4 waves -> 4 c values per block.z
-  const int cc = blockIdx.z * 4 + c;
-  if (cc >= C) return;
-  const long g0 = (long)blockIdx.x * chunk, g1 = g0 + chunk < G ? g0 + chunk : G;
-  float s = 0.f;
-  for (long gI = g0 + lane; gI < g1; gI += 64) s = fmaf(dth[(long)b * G + gI], W[(long)cc * G + gI], s);
-  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) unsafeAtomicAdd(dctx + (long)b * C + cc, s);
 }
 
 // ---- optimizer ------------------------------------------------------------------------------------
@@ -861,10 +998,8 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   bgemm(st, true, false, BG{ctx, tb.dtheta, Gm + L.wcat, nullptr, C, (int)G, B, C, (int)G, (int)G, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);   // dW_cat = ctx^T dtheta
   KL(colsum_kernel, dim3((unsigned)((G + 63) / 64), 1, (B + 63) / 64), dim3(64), tb.dtheta, Gm + L.bcat, 0, B, B, (int)G, 1);                  // db_cat
   (void)hipMemsetAsync(dctx, 0, (size_t)B * C * 4, st);
-  {
-    const int chunk = 8192;
-    KL(dctx_kernel, dim3((unsigned)((G + chunk - 1) / chunk), B, (C + 3) / 4), dim3(256), tb.dtheta, Pm + L.wcat, dctx, B, C, G, chunk);
-  }
+  // dctx = dtheta W_cat^T: [B, G] x [G, C], a K = 201 500 product onto a B x C output -> split-K over the whole chip
+  bgemm(st, false, true, BG{tb.dtheta, Pm + L.wcat, dctx, nullptr, B, C, (int)G, (int)G, (int)G, C, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);
   // =============================== context encoder backward ===============================
   (void)hipMemsetAsync(cdx, 0, (size_t)B * Sc * C * 4, st);
   KL(ctx_final_bwd_kernel, dim3((B + 3) / 4), dim3(256), cx_fin + (long)(Sc - 1) * C, (long)Sc * C, dctx, cmean, crstd, Pm + L.norm_s, cdx + (long)(Sc - 1) * C, Gm + L.norm_s, Gm + L.norm_b, B, C, g.scale_context ? 1.f / sqrtf((float)C) : 1.f);

@@ -261,3 +261,23 @@ def test_action_loss_matches_oracle(mid):
                                  batch["action_pad_mask"])
     np.testing.assert_allclose(per.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
     assert ref[1] == 0.0 and abs(float(mean) - ref_mean) < 1e-4
+
+def test_dinov2_small_geometry():
+    """BASELINE configs[1] names DINOv2-small tokens (E = 384, 6 heads, MLP 1536): the same kernels at the other
+    encoder width, end to end against the float64 restatement."""
+    from hypervla import synthetic as syn
+    from hypervla.config import SMALL_E, encoder_leaves, generated_leaves
+    from hypervla.model import HyperVLA
+    from oracle import hvla_ref_torch as ot
+    g, B = SMALL_E, 2
+    model = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    ref = ot.FullRef(model.params, g, generated_leaves(g), dict(encoder_leaves(g)), dtype=torch.float64)
+    theta, _ = ref.create_tasks(ins, st)
+    act, logit, _, tokens = ref.sample_actions(theta, im)
+    bp, tasks, _ = model.create_tasks(instruction_dict=ins, initial_state=st)
+    got, inter = model.sample_actions(im, ins, tasks, np.ones((B, 1)), base_params=bp)
+    np.testing.assert_allclose(model.encode_images(im).cpu().numpy(), tokens.numpy(), atol=2e-2)
+    mae = np.abs(np.asarray(got)[..., :6] - act.numpy()[..., :6]).mean()
+    print("DINOv2-small end-to-end action MAE", mae)
+    assert mae <= 1e-3                                            # north-star tolerance
