@@ -104,28 +104,35 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
 // The same product on the bf16 matrix cores at f32-class accuracy: every f32 operand element is split while it is
 // staged into LDS, x = hi + lo (two bf16, 16 mantissa bits together), and each 16-deep k chunk costs three
 // v_mfma_f32_32x32x16_bf16 (lo*hi + hi*lo + hi*hi; the dropped lo*lo term is 2^-16 relative) -- about 5x the f32
-// instruction's rate.  Both operands are staged k-contiguous ([row][k], 80-byte rows: conflict-free ds_read_b128
-// fragments) whatever their layout in memory; a transposed source is read along its contiguous dimension and turned
-// while it is written.  4 waves as 2 x 2, BM x BN in {128 x 128, 64 x 64}, register-prefetched k steps of 32.
+// instruction's rate.  Operands are staged without transposition whatever their layout in memory (see stage_load).
+// 4 waves as 2 x 2, BM x BN in {128 x 128, 64 x 64}, k steps of 32 with three steps of global loads in flight.
 // ------------------------------------------------------------------------------------------------
-template <bool T, int BR>
-__device__ __forceinline__ void stage_load(const float* __restrict__ P, int ld, int r0, int R, int k0, int kend, bool vec,
+// Staging of one BR x 32 operand tile (f32 in memory -> hi / lo bf16 planes in LDS), two flavours:
+//   T = false  source is k-contiguous (rows of 32 floats): LDS image [row][40]; fragments by ds_read_b128
+//   T = true   source is row-contiguous (memory [k][row]): LDS image [k][BR + 32], no transposition while staging;
+//              the fragment's k-in-lane order comes from ds_read_b64_tr_b16 (two per plane and k chunk)
+// Either way a thread moves float4's along the contiguous dimension (scalar fallback for unaligned / edge pieces).
+// Loads are branch-free (clamped address + select) so that the compiler keeps counted s_waitcnt vmcnt: VEC = one
+// float4 per piece (host guarantees 16-byte alignment and that pieces never straddle the K / row edge), else 4 dwords.
+template <bool T, int BR, bool VEC>
+__device__ __forceinline__ void stage_load(const float* __restrict__ P, int ld, int r0, int R, int k0, int kend,
                                            float4 (&out)[BR * 8 / 256]) {
 #pragma unroll
   for (int j = 0; j < BR * 8 / 256; ++j) {
     const int idx = threadIdx.x + j * 256;
-    const int row = T ? idx % BR : idx >> 3, kq = T ? (idx / BR) * 4 : (idx & 7) * 4;
-    const int r = r0 + row, k = k0 + kq;
-    float4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < R && k < kend) {
-      if (!T) {
-        const float* p = P + (long)r * ld + k;
-        if (vec && k + 3 < kend) v = *reinterpret_cast<const float4*>(p);
-        else { v.x = p[0]; if (k + 1 < kend) v.y = p[1]; if (k + 2 < kend) v.z = p[2]; if (k + 3 < kend) v.w = p[3]; }
-      } else {
-        const float* p = P + (long)k * ld + r;
-        v.x = p[0]; if (k + 1 < kend) v.y = p[ld]; if (k + 2 < kend) v.z = p[2 * (long)ld]; if (k + 3 < kend) v.w = p[3 * (long)ld];
-      }
+    const int r = r0 + (T ? (idx % (BR / 4)) * 4 : idx >> 3), k = k0 + (T ? idx / (BR / 4) : (idx & 7) * 4);
+    const bool ok = r < R && k < kend;
+    const long base = T ? (long)k * ld + r : (long)r * ld + k;
+    const long step = T ? 1 : 1;                          // the 4 elements of a piece are adjacent in memory either way
+    float4 v;
+    if (VEC) {
+      v = *reinterpret_cast<const float4*>(P + (ok ? base : 0));
+      if (!ok) v = float4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      const int lim = T ? R - r : kend - k;               // valid elements in this piece (<= 0: none)
+      const bool o0 = ok, o1 = ok && lim > 1, o2 = ok && lim > 2, o3 = ok && lim > 3;
+      const float x0 = P[o0 ? base : 0], x1 = P[o1 ? base + step : 0], x2 = P[o2 ? base + 2 * step : 0], x3 = P[o3 ? base + 3 * step : 0];
+      v = float4{o0 ? x0 : 0.f, o1 ? x1 : 0.f, o2 ? x2 : 0.f, o3 ? x3 : 0.f};
     }
     out[j] = v;
   }
@@ -135,22 +142,52 @@ __device__ __forceinline__ void stage_store(__bf16* __restrict__ hi, __bf16* __r
 #pragma unroll
   for (int j = 0; j < BR * 8 / 256; ++j) {
     const int idx = threadIdx.x + j * 256;
-    const int row = T ? idx % BR : idx >> 3, kq = T ? (idx / BR) * 4 : (idx & 7) * 4;
+    const int o = T ? (idx / (BR / 4)) * (BR + 32) + (idx % (BR / 4)) * 4 : (idx >> 3) * 40 + (idx & 7) * 4;
     bf16x4 h, l;
     __bf16 a, b;
     split1(in[j].x, a, b); h[0] = a; l[0] = b;
     split1(in[j].y, a, b); h[1] = a; l[1] = b;
     split1(in[j].z, a, b); h[2] = a; l[2] = b;
     split1(in[j].w, a, b); h[3] = a; l[3] = b;
-    *reinterpret_cast<bf16x4*>(hi + row * 40 + kq) = h;
-    *reinterpret_cast<bf16x4*>(lo + row * 40 + kq) = l;
+    *reinterpret_cast<bf16x4*>(hi + o) = h;
+    *reinterpret_cast<bf16x4*>(lo + o) = l;
   }
 }
+typedef short hvla_tr4 __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p0, const __bf16* p1) {   // p1 = 4 k rows below p0
+  const hvla_tr4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hvla_tr4*)p0);
+  const hvla_tr4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hvla_tr4*)p1);
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// fragment of the 32-row block starting at row rb, k chunk kk (0 / 16): lane l holds row rb + (l & 31), k = kk + 8 (l >> 5) + 0..7
+template <bool T, int BR>
+__device__ __forceinline__ Split8 load_frag(const __bf16* hi, const __bf16* lo, int rb, int kk, int lane) {
+  Split8 f;
+  if (!T) {
+    const int o = (rb + (lane & 31)) * 40 + kk + (lane >> 5) * 8;
+    f.hi = *reinterpret_cast<const bf16x8*>(hi + o);
+    f.lo = *reinterpret_cast<const bf16x8*>(lo + o);
+  } else {
+    // 16-lane group g = lane >> 4 covers rows rb + 16 (g & 1) .. + 15 at k half (g >> 1); lane 4q + p of the group
+    // addresses LDS row (k) q, columns 4p .. 4p + 3 and receives its own column of the four rows
+    constexpr int LDT = BR + 32;
+    const int i = lane & 15, q = i >> 2, pp = i & 3;
+    const int o = (kk + 8 * (lane >> 5) + q) * LDT + rb + 16 * ((lane >> 4) & 1) + 4 * pp;
+    f.hi = tr_frag(hi + o, hi + o + 4 * LDT);
+    f.lo = tr_frag(lo + o, lo + o + 4 * LDT);
+  }
+  return f;
+}
 
-template <bool TA, bool TB, int BM, int BN>
-__global__ __launch_bounds__(256) void bgemm3_kernel(BG g, int vecA, int vecB) {
-  constexpr int LD = 40, WM = BM / 2, WN = BN / 2, IM = WM / 32, IN = WN / 32;
-  __shared__ __attribute__((aligned(16))) __bf16 Ah[BM * LD], Al[BM * LD], Bh[BN * LD], Bl[BN * LD];
+template <bool TA, bool TB, int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
+  constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, IN = WN / 32;
+  constexpr bool SA = TA, SB = !TB;                       // staging flavour: row-contiguous source?
+  constexpr int NA = SA ? 32 * (BM + 32) : BM * 40, NB = SB ? 32 * (BN + 32) : BN * 40;
+  constexpr int NST = 3;                                  // k steps of global loads in flight (register stages)
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[NA], Al[NA], Bh[NB], Bl[NB];
   const int zb = blockIdx.z / g.ksplit, kc = blockIdx.z % g.ksplit;
   const int b0 = zb / g.nb1, b1 = zb % g.nb1;
   const int kchunk = ((g.K + g.ksplit - 1) / g.ksplit + 31) & ~31;
@@ -168,39 +205,38 @@ __global__ __launch_bounds__(256) void bgemm3_kernel(BG g, int vecA, int vecB) {
     for (int b = 0; b < IN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float4 ra[BM * 8 / 256], rb[BN * 8 / 256];
-  if (kbeg < kend) {
-    stage_load<TA, BM>(A, g.lda, m0, g.M, kbeg, kend, vecA != 0, ra);
-    stage_load<!TB, BN>(B, g.ldb, n0, g.N, kbeg, kend, vecB != 0, rb);
+  float4 ra[NST][BM * 8 / 256], rb[NST][BN * 8 / 256];
+#pragma unroll
+  for (int s2 = 0; s2 < NST; ++s2) {                      // out-of-range steps load zeros (k >= kend)
+    stage_load<SA, BM, VEC>(A, g.lda, m0, g.M, kbeg + 32 * s2, kend, ra[s2]);
+    stage_load<SB, BN, VEC>(B, g.ldb, n0, g.N, kbeg + 32 * s2, kend, rb[s2]);
   }
-  for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    __syncthreads();                                     // the previous step's fragment reads are done
-    stage_store<TA, BM>(Ah, Al, ra);
-    stage_store<!TB, BN>(Bh, Bl, rb);
-    __syncthreads();
-    if (k0 + 32 < kend) {                                // next step's global loads fly under this step's MFMAs
-      stage_load<TA, BM>(A, g.lda, m0, g.M, k0 + 32, kend, vecA != 0, ra);
-      stage_load<!TB, BN>(B, g.ldb, n0, g.N, k0 + 32, kend, vecB != 0, rb);
-    }
+  // Straight-line body (no branch around the refill loads): the compiler can then wait for exactly the oldest
+  // register stage with a counted s_waitcnt vmcnt while the two younger stages stay in flight.
+  for (int k0 = kbeg; k0 < kend; k0 += 32 * NST) {
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 16) {
-      Split8 fa[IM], fb[IN];
+    for (int s2 = 0; s2 < NST; ++s2) {
+      const int kcur = k0 + 32 * s2;
+      if (kcur >= kend) break;                            // uniform over the workgroup; leaves the loop for good
+      __syncthreads();                                    // the previous step's fragment reads are done
+      stage_store<SA, BM>(Ah, Al, ra[s2]);
+      stage_store<SB, BN>(Bh, Bl, rb[s2]);
+      __syncthreads();
+      // refill this register stage NST steps ahead (lanes past kend just get zeros)
+      stage_load<SA, BM, VEC>(A, g.lda, m0, g.M, kcur + 32 * NST, kend, ra[s2]);
+      stage_load<SB, BN, VEC>(B, g.ldb, n0, g.N, kcur + 32 * NST, kend, rb[s2]);
 #pragma unroll
-      for (int a = 0; a < IM; ++a) {
-        const int o = (wm * WM + a * 32 + col) * LD + kk + half * 8;
-        fa[a].hi = *reinterpret_cast<const bf16x8*>(Ah + o);
-        fa[a].lo = *reinterpret_cast<const bf16x8*>(Al + o);
+      for (int kk = 0; kk < 32; kk += 16) {
+        Split8 fa[IM], fb[IN];
+#pragma unroll
+        for (int a = 0; a < IM; ++a) fa[a] = load_frag<SA, BM>(Ah, Al, wm * WM + a * 32, kk, lane);
+#pragma unroll
+        for (int b = 0; b < IN; ++b) fb[b] = load_frag<SB, BN>(Bh, Bl, wn * WN + b * 32, kk, lane);
+#pragma unroll
+        for (int a = 0; a < IM; ++a)
+#pragma unroll
+          for (int b = 0; b < IN; ++b) acc[a][b] = mma32_x3(fa[a], fb[b], acc[a][b]);
       }
-#pragma unroll
-      for (int b = 0; b < IN; ++b) {
-        const int o = (wn * WN + b * 32 + col) * LD + kk + half * 8;
-        fb[b].hi = *reinterpret_cast<const bf16x8*>(Bh + o);
-        fb[b].lo = *reinterpret_cast<const bf16x8*>(Bl + o);
-      }
-#pragma unroll
-      for (int a = 0; a < IM; ++a)
-#pragma unroll
-        for (int b = 0; b < IN; ++b) acc[a][b] = mma32_x3(fa[a], fb[b], acc[a][b]);
     }
   }
   const float* bias = g.bias && kc == 0 ? g.bias + b0 * g.sBias0 : nullptr;
@@ -223,12 +259,12 @@ __global__ __launch_bounds__(256) void bgemm3_kernel(BG g, int vecA, int vecB) {
   }
 }
 
-template <int BM, int BN>
-static void launch_bgemm3(hipStream_t st, bool ta, bool tb, const BG& g, dim3 grid, int va, int vb) {
-  if (!ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<false, false, BM, BN>), grid, dim3(256), 0, st, g, va, vb);
-  else if (!ta && tb) hipLaunchKernelGGL((bgemm3_kernel<false, true, BM, BN>), grid, dim3(256), 0, st, g, va, vb);
-  else if (ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<true, false, BM, BN>), grid, dim3(256), 0, st, g, va, vb);
-  else hipLaunchKernelGGL((bgemm3_kernel<true, true, BM, BN>), grid, dim3(256), 0, st, g, va, vb);
+template <int BM, int BN, bool VEC>
+static void launch_bgemm3(hipStream_t st, bool ta, bool tb, const BG& g, dim3 grid) {
+  if (!ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<false, false, BM, BN, VEC>), grid, dim3(256), 0, st, g);
+  else if (!ta && tb) hipLaunchKernelGGL((bgemm3_kernel<false, true, BM, BN, VEC>), grid, dim3(256), 0, st, g);
+  else if (ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<true, false, BM, BN, VEC>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((bgemm3_kernel<true, true, BM, BN, VEC>), grid, dim3(256), 0, st, g);
 }
 
 // HVLA_TRAIN_GEMM=f32 selects the exact-f32 matrix instruction (bitwise fmaf chains) instead of the split-bf16 path
@@ -250,11 +286,14 @@ static void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
   }
   dim3 grid((g.N + T - 1) / T, (g.M + T - 1) / T, nb0 * g.nb1 * g.ksplit);
   if (!exact) {
-    // float4 staging needs 16-byte aligned rows of the k-contiguous operands
-    auto al = [](const float* p, int ld, long s0, long s1) { return ((uintptr_t)p % 16 == 0) && ld % 4 == 0 && s0 % 4 == 0 && s1 % 4 == 0; };
-    const int va = !ta && al(g.A, g.lda, g.sA0, g.sA1), vb = tb && al(g.B, g.ldb, g.sB0, g.sB1);
-    if (T == 128) launch_bgemm3<128, 128>(st, ta, tb, g, grid, va, vb);
-    else launch_bgemm3<64, 64>(st, ta, tb, g, grid, va, vb);
+    // float4 staging: 16-byte aligned pieces that never straddle an edge (k-contiguous operand: K % 4 == 0;
+    // row-contiguous operand: its row count % 4 == 0); otherwise the all-dword variant
+    auto al = [](const float* p, int ld, long s0, long s1, int extent) {
+      return ((uintptr_t)p % 16 == 0) && ld % 4 == 0 && s0 % 4 == 0 && s1 % 4 == 0 && extent % 4 == 0;
+    };
+    const bool vec = al(g.A, g.lda, g.sA0, g.sA1, ta ? g.M : g.K) && al(g.B, g.ldb, g.sB0, g.sB1, tb ? g.K : g.N);
+    if (T == 128) { if (vec) launch_bgemm3<128, 128, true>(st, ta, tb, g, grid); else launch_bgemm3<128, 128, false>(st, ta, tb, g, grid); }
+    else { if (vec) launch_bgemm3<64, 64, true>(st, ta, tb, g, grid); else launch_bgemm3<64, 64, false>(st, ta, tb, g, grid); }
     return;
   }
   if (!ta && !tb) hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, dim3(256), 0, st, g);
