@@ -128,6 +128,8 @@ def main():
                     help="DINOv2-base (README / reference parity, default) or DINOv2-small (E=384, BASELINE configs[1] wording)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (BASELINE config 3)")
+    ap.add_argument("--ensemble", action="store_true",
+                    help="include the device-side un-normalise + temporal ensemble in every step (always on with --graph)")
     ap.add_argument("--finetune", action="store_true",
                     help="BASELINE config 5: encode + fwd + bwd + RCCL grad all-reduce + AdamW + EMA (encoder frozen "
                          "unless --train-encoder)")
@@ -171,8 +173,18 @@ def main():
     logits = torch.empty(B, g.horizon, device=dev)
     stream = model._stream()
 
+    ens = None
+    if a.graph or a.ensemble:          # BASELINE configs[2]: the device-side un-normalise + temporal ensemble is
+        stats = syn.synthetic_dataset_statistics(g)["bridge_dataset"]["action"]     # part of the captured step
+        ens = (torch.as_tensor(stats["mean"]).to(dev), torch.as_tensor(stats["std"]).to(dev),
+               torch.as_tensor(stats["mask"].astype(np.uint8)).to(dev), torch.empty(B, g.action_dim, device=dev))
+        ctx.ensemble_reset(w._h, stream)
+
     def step():
         ctx.step(w._h, images.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, stream)
+        if ens is not None:
+            ctx.ensemble(w._h, actions.data_ptr(), ens[0].data_ptr(), ens[1].data_ptr(), ens[2].data_ptr(),
+                         ens[3].data_ptr(), stream)
 
     for _ in range(a.warmup):
         step()
@@ -213,7 +225,8 @@ def main():
 
     # ---- per-step latency distribution + full kernel breakdown (separate, un-timed passes)
     lat = []
-    for _ in range(min(a.steps, 20)):
+    n_lat = max(a.steps, 200) if a.graph else min(a.steps, 20)      # config 3: p50 over >= 200 replays
+    for _ in range(n_lat):
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         step()
@@ -259,13 +272,17 @@ def main():
         "metric": "actions_per_sec", "value": round(whole_job_rate(B, world, a.steps, elapsed), 2), "unit": "actions/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.enc_dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: hypernet weight-gen once (untimed) + full sample_actions step "
+        "config": {"workload": ("BASELINE configs[2] (hipGraph-captured step incl. device-side ensemble): " if a.graph else
+                                "BASELINE configs[1]: ") + "hypernet weight-gen once (untimed) + full sample_actions step "
                                f"(u8 224x224 -> DINOv2-{a.encoder} E={g.enc_dim} in the loop -> generated vit_t 4L/64d policy -> "
                                "[4,7] action chunk); 1 action = 1 sample-step",
                    "batch_per_gpu": B, "global_batch": world * B, "encoder": "DINOv2-base (reference parity, E=768)" if a.encoder == "base" else "DINOv2-small (E=384)",
                    "parallelism": f"episode-dp{world} (no collectives)",
                    "encoder_operands": a.enc_dtype, "policy_operands": "split-bf16 (bf16x3)",
-                   "launch": "hipGraph replay" if a.graph else "eager (about 95 launches per step)"},
+                   "launch": "hipGraph replay" if a.graph else "eager (about 95 launches per step)",
+                   "ensemble": "device-side un-normalise + temporal ensemble (history = horizon) inside the step"
+                               if ens is not None else "not in the step"},
+        "latency_samples": len(lat),
         "p50_step_latency_ms": round(float(np.median(lat)), 4),
         "roofline": {"bound": "mfma", "kernel": f"gemm256r_kernel<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",
                      "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
