@@ -218,10 +218,11 @@ __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
     for (int s2 = 0; s2 < NST; ++s2) {
       const int kcur = k0 + 32 * s2;
       if (kcur >= kend) break;                            // uniform over the workgroup; leaves the loop for good
-      __syncthreads();                                    // the previous step's fragment reads are done
+      // raw barriers: a __syncthreads() would also drain the two younger register stages' global loads (vmcnt(0))
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the previous step's fragment reads are done
       stage_store<SA, BM>(Ah, Al, ra[s2]);
       stage_store<SB, BN>(Bh, Bl, rb[s2]);
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the LDS image is complete
       // refill this register stage NST steps ahead (lanes past kend just get zeros)
       stage_load<SA, BM, VEC>(A, g.lda, m0, g.M, kcur + 32 * NST, kend, ra[s2]);
       stage_load<SB, BN, VEC>(B, g.ldb, n0, g.N, kcur + 32 * NST, kend, rb[s2]);
@@ -275,7 +276,9 @@ static bool train_gemm_exact() {
 
 static void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
   const bool exact = train_gemm_exact();
-  const int T = !exact && g.M >= 96 && g.N >= 96 ? 128 : 64;
+  static const long min128 = [] { const char* e = getenv("HVLA_MIN128"); return e ? atol(e) : 0L; }();
+  int T = !exact && g.M >= 96 && g.N >= 96 ? 128 : 64;
+  if (T == 128 && (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * nb0 * g.nb1 * (g.accumulate ? 8 : 1) < min128) T = 64;
   // deep-K products onto few output tiles (shared-weight gradients: K = all rows of the batch) would leave most CUs
   // idle: cut K so that the grid has >= ~256 workgroups (one per CU; more only adds atomic traffic); legal whenever the result is accumulated (C zeroed before)
   const long tiles = (long)((g.N + T - 1) / T) * ((g.M + T - 1) / T) * nb0 * g.nb1;
