@@ -458,6 +458,17 @@ int hvla_encode(hvla_ctx* ctx, const uint8_t* images, float* tokens, int32_t B, 
   return HVLA_OK;
 }
 
+int hvla_encode_hidden(hvla_ctx* ctx, const uint8_t* images, float* hidden, int32_t B, void* stream) {
+  if (!ctx) return HVLA_E_STATE;
+  if (int r = check_step(ctx, B)) return r;
+  if (!images || !hidden) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p};
+  HIPCHK(ctx, launch_encoder(ctx->g, ctx->cfg.enc_dtype, ctx->encw, ws, images, hidden, B,
+                             reinterpret_cast<hipStream_t>(stream), &ctx->prof, true));
+  return HVLA_OK;
+}
+
 int hvla_policy(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float* actions, float* logits, int32_t B,
                 void* stream) {
   if (!ctx || !w) return HVLA_E_STATE;

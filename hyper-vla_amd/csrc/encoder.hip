@@ -669,13 +669,15 @@ __global__ __launch_bounds__(WM * 256) void gemm256r_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row of E f32 (E % 4 == 0, E <= 1024); FINAL drops row 0 of every image and
 // writes f32.
-template <typename Op, bool FINAL>
+// FINAL: 0 = 16-bit output for the next GEMM; 1 = f32 patch tokens with the CLS row dropped (base_vit.py:120-122);
+//        2 = f32 last_hidden_state with every row (the evaluators' initial-image embedding)
+template <typename Op, int FINAL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, void* __restrict__ out,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ bias, int M, int E, int S) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  if (FINAL && (row % S) == 0) return;
+  if (FINAL == 1 && (row % S) == 0) return;
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * E);
   const int n4 = E / 4;
   f32x4 v[4];
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
   const float rstd = rsqrtf(sq / E + 1e-6f);
   size_t orow = row;
-  if (FINAL) orow = (size_t)(row / S) * (S - 1) + (row % S) - 1;
+  if (FINAL == 1) orow = (size_t)(row / S) * (S - 1) + (row % S) - 1;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = lane + 64 * i;
@@ -914,7 +916,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 // ------------------------------------------------------------------------------------------------
 template <typename Op>
 static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorkspace& ws, const uint8_t* images,
-                              float* tokens, int B, hipStream_t st, Profiler* prof) {
+                              float* tokens, int B, hipStream_t st, Profiler* prof, bool keep_cls) {
   Profiler none;
   Profiler& pf = prof ? *prof : none;
   using T = typename Op::elem;
@@ -993,7 +995,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   for (int l = 0; l < g.enc_layers; ++l) {
     const EncLayerW& L = w.layer[l];
     pf.begin(1, st);
-    hipLaunchKernelGGL((layernorm_kernel<Op, false>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln1_s,
+    hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln1_s,
                        L.ln1_b, M, E, S);
     pf.end(1, st);
     pf.begin(2, st);
@@ -1007,7 +1009,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
     pf.end(4, st);
     pf.begin(1, st);
-    hipLaunchKernelGGL((layernorm_kernel<Op, false>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln2_s,
+    hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln2_s,
                        L.ln2_b, M, E, S);
     pf.end(1, st);
     pf.begin(5, st);
@@ -1018,8 +1020,10 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     pf.end(6, st);
   }
   pf.begin(1, st);
-  hipLaunchKernelGGL((layernorm_kernel<Op, true>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s,
-                     w.lnf_b, M, E, S);
+  if (keep_cls)
+    hipLaunchKernelGGL((layernorm_kernel<Op, 2>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s, w.lnf_b, M, E, S);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<Op, 1>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s, w.lnf_b, M, E, S);
   pf.end(1, st);
   return hipGetLastError();
 }
@@ -1091,9 +1095,9 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
 }
 
 hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const EncWorkspace& ws,
-                          const uint8_t* images, float* tokens, int B, hipStream_t st, Profiler* prof) {
-  if (dtype == 1) return run_encoder<OpBF16>(g, w, ws, images, tokens, B, st, prof);
-  return run_encoder<OpF16>(g, w, ws, images, tokens, B, st, prof);
+                          const uint8_t* images, float* tokens, int B, hipStream_t st, Profiler* prof, bool keep_cls) {
+  if (dtype == 1) return run_encoder<OpBF16>(g, w, ws, images, tokens, B, st, prof, keep_cls);
+  return run_encoder<OpF16>(g, w, ws, images, tokens, B, st, prof, keep_cls);
 }
 
 }  // namespace hvla

@@ -81,7 +81,8 @@ struct Profiler {
   }
 };
 hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const EncWorkspace& ws,
-                          const uint8_t* images, float* tokens, int B, hipStream_t st, Profiler* prof);
+                          const uint8_t* images, float* tokens, int B, hipStream_t st, Profiler* prof,
+                          bool keep_cls = false);   // keep_cls: tokens = f32 [B, S, E] last_hidden_state
 
 hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st);

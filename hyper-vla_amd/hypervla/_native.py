@@ -18,7 +18,7 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_generate", "hvla_weights_free", "hvla_weights_batch", "hvla_weights_export",
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
-           "hvla_train_sizes", "hvla_train_step", "hvla_train_apply"]
+           "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy"]
 
 
@@ -83,6 +83,8 @@ def load_library():
     lib.hvla_weights_export.restype = C.c_int
     lib.hvla_encode.argtypes = [vp, vp, vp, i32, vp]
     lib.hvla_encode.restype = C.c_int
+    lib.hvla_encode_hidden.argtypes = [vp, vp, vp, i32, vp]
+    lib.hvla_encode_hidden.restype = C.c_int
     lib.hvla_policy.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.hvla_policy.restype = C.c_int
     lib.hvla_step.argtypes = [vp, vp, vp, vp, vp, i32, vp]
@@ -192,6 +194,9 @@ class Context:
 
     def encode(self, img_ptr, tok_ptr, B, stream=0):
         self._check(self.lib.hvla_encode(self.h, img_ptr, tok_ptr, B, C.c_void_p(stream)), "hvla_encode")
+
+    def encode_hidden(self, img_ptr, hidden_ptr, B, stream=0):
+        self._check(self.lib.hvla_encode_hidden(self.h, img_ptr, hidden_ptr, B, C.c_void_p(stream)), "hvla_encode_hidden")
 
     def policy(self, w, tok_ptr, act_ptr, logit_ptr, B, stream=0):
         self._check(self.lib.hvla_policy(self.h, w, tok_ptr, act_ptr, logit_ptr, B, C.c_void_p(stream)), "hvla_policy")

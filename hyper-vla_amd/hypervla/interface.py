@@ -99,6 +99,14 @@ class InferenceWrapper:
                                       f"pass {self.image_size}x{self.image_size} uint8 frames")
         return image
 
+    def initial_state_from_image(self, image: np.ndarray):
+        """The dict the evaluators assemble before `reset` (data/simpler/evaluate.py:264-274), with the DINOv2
+        `last_hidden_state` of the first frame computed on the device instead of by a host-side HF Flax model."""
+        frame = self._resize_image(image)
+        hidden = self.model.encode_initial_image(frame[None])
+        return {"image_primary": frame, "patch_embeddings": hidden,
+                "pad_mask_dict": {"image_primary": np.ones((1, 1))}}
+
     def reset(self, task_description: str, instruction_dict, initial_state=None) -> None:
         self.base_params, self.task, _ = self.model.create_tasks(instruction_dict=instruction_dict,
                                                                  initial_state=initial_state)

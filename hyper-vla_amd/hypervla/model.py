@@ -233,6 +233,21 @@ class HyperVLA:
         self._ctx.encode(img.data_ptr(), tokens.data_ptr(), B, self._stream())
         return tokens
 
+    def encode_initial_image(self, images):
+        """The evaluators' `DINO_encode_image(initial_image).last_hidden_state` on the device
+        (data/simpler/evaluate.py:155-163,264-274): uint8 [B, (1,) H, W, 3] -> f32 [B, 1 + P, E] (row 0 = CLS), ready to
+        be passed as ``initial_state["patch_embeddings"]``.  Uses the DINOv2 weights of this checkpoint (the
+        evaluators use the pretrained ones, which are the same tensors unless the encoder was fine-tuned)."""
+        torch = _torch()
+        g = self.geometry
+        img = self._dev(images, torch.uint8)
+        if img.dim() == 5:
+            img = img[:, 0].contiguous()
+        B = img.shape[0]
+        hidden = torch.empty(B, g.patches + 1, g.enc_dim, dtype=torch.float32, device=self.device)
+        self._ctx.encode_hidden(img.data_ptr(), hidden.data_ptr(), B, self._stream())
+        return hidden
+
     def policy_from_tokens(self, tokens, base_params: GeneratedWeights):
         torch = _torch()
         g = self.geometry

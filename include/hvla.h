@@ -99,6 +99,12 @@ int hvla_weights_export(hvla_ctx* ctx, const hvla_weights* w, float* theta, floa
  * (hypervla/components/base_vit.py:109-122).  images u8 [B, H, W, 3] -> tokens f32 [B, P, E].   */
 int hvla_encode(hvla_ctx* ctx, const uint8_t* images, float* tokens, int32_t B, void* stream);
 
+/* Replaces: the evaluators' `DINO_encode_image(initial_image).last_hidden_state`, the source of
+ * initial_state["patch_embeddings"] whose CLS row conditions the hypernetwork
+ * (data/simpler/evaluate.py:155-163,264-274; data/libero/evaluate.py:175; scripts/train.py:417-419), run with the
+ * DINOv2 weights loaded into this ctx.  images u8 [B, H, W, 3] -> hidden f32 [B, 1 + P, E] (row 0 = CLS).   */
+int hvla_encode_hidden(hvla_ctx* ctx, const uint8_t* images, float* hidden, int32_t B, void* stream);
+
 /* Replaces: the rest of BaseNetwork.predict_action with per-episode weights
  * (base_vit.py:130-227, transformer.py:127-262, action_heads.py:431-472,524-538).
  *   tokens f32 [B, P, E] -> actions f32 [B, horizon, action_dim]; gripper_logits f32 [B, horizon]

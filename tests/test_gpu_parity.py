@@ -281,3 +281,23 @@ def test_dinov2_small_geometry():
     mae = np.abs(np.asarray(got)[..., :6] - act.numpy()[..., :6]).mean()
     print("DINOv2-small end-to-end action MAE", mae)
     assert mae <= 1e-3                                            # north-star tolerance
+
+
+def test_initial_image_hidden_state(mid):
+    """hvla_encode_hidden = last_hidden_state with the CLS row (the evaluators' initial-image embedding); feeding it
+    back as initial_state reproduces create_tasks from the oracle's embedding within the fp16-encoder error."""
+    from hypervla.config import encoder_leaves
+    from oracle import hvla_ref_np as onp
+    m, g = mid["model"], mid["g"]
+    hid = m.encode_initial_image(mid["im"])
+    ref = onp.dinov2(mid["P"], g, dict(encoder_leaves(g)), onp.normalize_images(mid["im"][:, 0]))
+    assert tuple(hid.shape) == ref.shape
+    d = hid.cpu().numpy().astype(np.float64) - ref
+    assert np.sqrt((d * d).mean()) <= 2e-3 and np.abs(d).max() <= 2e-2
+    np.testing.assert_array_equal(hid[:, 1:].cpu().numpy(), m.encode_images(mid["im"]).cpu().numpy())
+    st_dev = {"patch_embeddings": hid, "pad_mask_dict": {"image_primary": np.ones((mid["B"], 1))}}
+    st_ref = {"patch_embeddings": ref.astype(np.float32), "pad_mask_dict": st_dev["pad_mask_dict"]}
+    w_dev, _, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=st_dev)
+    w_ref, _, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=st_ref)
+    th_dev, th_ref = w_dev.export()[0], w_ref.export()[0]
+    assert float((th_dev - th_ref).abs().max()) <= 5e-3
