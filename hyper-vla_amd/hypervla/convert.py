@@ -1,0 +1,228 @@
+"""Checkpoint conversion for the built path: reference artefacts -> ``params_<step>.npz``.
+
+What can be read without JAX / Orbax in the process:
+
+* ``EMA_params.pkl`` (``scripts/train.py:697-699``: ``pickle.dump({"EMA_0.999": params})`` of **jax arrays**) — the
+  file the evaluators actually load (``data/simpler/evaluate.py:440-444``).  jax pickles an array as
+  ``jax._src.array._reconstruct_array(numpy_reduce_fn, numpy_reduce_args, array_state, aval_state)``; the shim
+  unpickler below rebuilds the numpy value and drops the device placement, so neither jax nor jaxlib is needed.
+* a flax parameter tree already on the host (nested dict of arrays; e.g. ``orbax`` restore output handed over by a
+  process that has JAX) — :func:`params_from_tree`.
+* the pretrained DINOv2 weights as a Hugging Face **torch** ``state_dict`` (``facebook/dinov2-base``) —
+  :func:`dinov2_from_hf_state_dict`, including the position-embedding table baked from HF's 37 x 37 grid to the run-time
+  16 x 16 grid exactly as ``FlaxDinov2Embeddings.interpolate_pos_encoding`` computes it on every call
+  (``jax.image.scale_and_translate(method="bicubic", antialias=False)`` with the ``+0.1`` size offset).
+
+Orbax step directories themselves (OCDBT / tensorstore) are not parsed here; export them where JAX exists with
+``tools/export_reference_checkpoint.py``.
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+import pickle
+import shutil
+from typing import Any, Dict, Mapping, Optional
+
+import numpy as np
+
+from .config import Geometry, encoder_leaves, geometry_from_config, hypernet_param_shapes, shared_name
+
+
+# ------------------------------------------------------------------------------------------------ pickles of jax arrays
+def _reconstruct_array(fun, args, arr_state, aval_state):
+    """Stand-in for ``jax._src.array._reconstruct_array``: the first three arguments are numpy's own pickle recipe."""
+    value = fun(*args)
+    value.__setstate__(arr_state)
+    return value
+
+
+class _JaxFreeUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if name == "_reconstruct_array" and module.startswith("jax"):
+            return _reconstruct_array
+        if module.startswith("jax") or module.startswith("jaxlib"):
+            raise pickle.UnpicklingError(f"unsupported jax object in pickle: {module}.{name}")
+        return super().find_class(module, name)
+
+
+def load_jax_pickle(path_or_bytes) -> Any:
+    """``pickle.load`` for files that contain jax arrays, without jax."""
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        return _JaxFreeUnpickler(io.BytesIO(path_or_bytes)).load()
+    with open(path_or_bytes, "rb") as f:
+        return _JaxFreeUnpickler(f).load()
+
+
+def load_ema_pickle(path: str, coefficient: float = 0.999) -> Dict[str, Any]:
+    """The tree the evaluators swap in with ``model.replace(params=EMA_params[f"EMA_{coefficient}"])``."""
+    trees = load_jax_pickle(path)
+    key = f"EMA_{coefficient}"
+    if key not in trees:
+        raise KeyError(f"{key} not in {sorted(trees)}")
+    return trees[key]
+
+
+# ------------------------------------------------------------------------------------------------ flax tree -> flat names
+def flatten_tree(tree: Mapping, sep: str = "/") -> Dict[str, np.ndarray]:
+    """``flax.traverse_util.flatten_dict(tree, sep=sep)`` for nested dicts (FrozenDict iterates the same way)."""
+    out: Dict[str, np.ndarray] = {}
+
+    def walk(node, prefix):
+        if isinstance(node, Mapping) or hasattr(node, "items"):
+            for k, v in node.items():
+                walk(v, prefix + [str(k)])
+        else:
+            out[sep.join(prefix)] = np.asarray(node)
+
+    walk(tree, [])
+    return out
+
+
+def params_from_tree(tree: Mapping, g: Geometry) -> Dict[str, np.ndarray]:
+    """Hypernetwork parameter tree (SURVEY.md §5.4 naming) -> the flat float32 dict `HyperVLA(params=...)` takes.
+    Every tensor the built path needs must be present with the expected shape; tensors the path does not use are
+    reported, not silently dropped."""
+    flat = flatten_tree(tree)
+    if flat and all(k.startswith("params/") for k in flat):             # a variables dict {"params": ...}
+        flat = {k[len("params/"):]: v for k, v in flat.items()}
+    shapes = hypernet_param_shapes(g)
+    missing = sorted(set(shapes) - set(flat))
+    if missing:
+        raise KeyError(f"{len(missing)} tensors missing from the checkpoint, e.g. {missing[:4]}")
+    extra = sorted(set(flat) - set(shapes))
+    if extra:
+        raise ValueError(f"{len(extra)} tensors of the checkpoint are outside the built path (other generation strategy / "
+                         f"encoder?), e.g. {extra[:4]}")
+    out = {}
+    for k, shp in shapes.items():
+        v = np.asarray(flat[k], np.float32)
+        if k.endswith("embeddings_position_embeddings") and v.size != int(np.prod(shp)):
+            # the checkpoint carries HF's 37 x 37 table; the reference resizes it inside every forward pass
+            v = bake_position_embeddings(v.reshape(1, -1, g.enc_dim), g.image_size // g.patch)
+        if int(np.prod(v.shape)) != int(np.prod(shp)):
+            raise ValueError(f"{k}: checkpoint shape {v.shape} != expected {tuple(shp)}")
+        out[k] = v.reshape(shp)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ DINOv2 position table
+def _cubic_kernel(x: np.ndarray) -> np.ndarray:
+    """Keys cubic convolution kernel, a = -0.5 (jax.image 'bicubic' == 'cubic'; torch's bicubic uses a = -0.75)."""
+    x = np.abs(x)
+    out = ((1.5 * x - 2.5) * x) * x + 1.0
+    out = np.where(x >= 1.0, ((-0.5 * x + 2.5) * x - 4.0) * x + 2.0, out)
+    return np.where(x >= 2.0, 0.0, out)
+
+
+def _scale_and_translate_weights(in_size: int, out_size: int, scale: float, translation: float = 0.0) -> np.ndarray:
+    """[in_size, out_size] weight matrix of jax.image.scale_and_translate for one spatial axis, antialias=False
+    (`jax/_src/image/scale.py::compute_weight_mat`): sample position of output i is (i + 0.5) / scale - t / scale - 0.5,
+    weights renormalised over the taps that exist, zero for samples outside [-0.5, in_size - 0.5]."""
+    inv = np.float32(1.0) / np.float32(scale)
+    sample_f = (np.arange(out_size, dtype=np.float32) + np.float32(0.5)) * inv - np.float32(translation) * inv - np.float32(0.5)
+    x = np.abs(sample_f[None, :] - np.arange(in_size, dtype=np.float32)[:, None])      # kernel_scale = 1 without antialias
+    w = _cubic_kernel(x.astype(np.float32)).astype(np.float32)
+    total = w.sum(axis=0, keepdims=True)
+    w = np.where(np.abs(total) > 1000.0 * np.finfo(np.float32).eps, w / np.where(total != 0, total, 1), 0.0)
+    inside = (sample_f >= -0.5) & (sample_f <= in_size - 0.5)
+    return np.where(inside[None, :], w, 0.0).astype(np.float32)
+
+
+def bake_position_embeddings(table: np.ndarray, grid: int) -> np.ndarray:
+    """HF ``embeddings.position_embeddings`` [1, 1 + n*n, E] -> [1, 1 + grid*grid, E] as
+    ``FlaxDinov2Embeddings.interpolate_pos_encoding`` produces it for a (14*grid)^2 image: the patch part is resized
+    with scale (grid + 0.1) / n per axis, translation 0, bicubic, no antialiasing, in float32; the class row is kept."""
+    table = np.asarray(table, np.float32)
+    if table.ndim == 2:
+        table = table[None]
+    n2, E = table.shape[1] - 1, table.shape[2]
+    n = int(round(np.sqrt(n2)))
+    if n * n != n2:
+        raise ValueError(f"position table has {n2} patch rows, not a square")
+    if n == grid:
+        return table.copy()
+    w = _scale_and_translate_weights(n, grid, np.float32((grid + 0.1) / n))           # same for rows and columns
+    patch = table[0, 1:].reshape(n, n, E)
+    # jax contracts the height axis first, then the width axis (spatial_dims order), each in float32
+    tmp = np.einsum("hwe,hi->iwe", patch, w, dtype=np.float32)
+    out = np.einsum("iwe,wj->ije", tmp, w, dtype=np.float32)
+    return np.concatenate([table[:, :1], out.reshape(1, grid * grid, E)], axis=1)
+
+
+# ------------------------------------------------------------------------------------------------ HF torch DINOv2 -> shared leaves
+def dinov2_from_hf_state_dict(sd: Mapping[str, Any], g: Geometry) -> Dict[str, np.ndarray]:
+    """``Dinov2Model.state_dict()`` (torch layout) -> the checkpoint's shared leaves: flat float32 vectors named
+    ``encoder_image_encoder_<path>`` in flax layout (Linear weights transposed to [in, out], conv OIHW -> HWIO),
+    position table baked to the geometry's grid (`hypervla/model.py:330-346,543-565`)."""
+    def arr(name):
+        v = sd[name]
+        v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        return np.asarray(v, np.float32)
+
+    out: Dict[str, np.ndarray] = {}
+
+    def put(path, v, shape):
+        v = np.ascontiguousarray(v, np.float32)
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError(f"{'/'.join(path)}: {v.shape} != {tuple(shape)}")
+        out[shared_name(path)] = v.reshape(-1)
+
+    shapes = dict(encoder_leaves(g))
+    E = g.enc_dim
+    put(("embeddings", "cls_token"), arr("embeddings.cls_token"), shapes[("embeddings", "cls_token")])
+    put(("embeddings", "mask_token"), arr("embeddings.mask_token"), shapes[("embeddings", "mask_token")])
+    put(("embeddings", "position_embeddings"), bake_position_embeddings(arr("embeddings.position_embeddings"), g.image_size // g.patch),
+        shapes[("embeddings", "position_embeddings")])
+    put(("embeddings", "patch_embeddings", "projection", "kernel"),
+        arr("embeddings.patch_embeddings.projection.weight").transpose(2, 3, 1, 0), (g.patch, g.patch, 3, E))
+    put(("embeddings", "patch_embeddings", "projection", "bias"), arr("embeddings.patch_embeddings.projection.bias"), (E,))
+    for i in range(g.enc_layers):
+        L, T = ("encoder", "layer", str(i)), f"encoder.layer.{i}."
+        for nm in ("norm1", "norm2"):
+            put(L + (nm, "scale"), arr(T + nm + ".weight"), (E,))
+            put(L + (nm, "bias"), arr(T + nm + ".bias"), (E,))
+        for nm in ("query", "key", "value"):
+            put(L + ("attention", "attention", nm, "kernel"), arr(T + f"attention.attention.{nm}.weight").T, (E, E))
+            put(L + ("attention", "attention", nm, "bias"), arr(T + f"attention.attention.{nm}.bias"), (E,))
+        put(L + ("attention", "output", "dense", "kernel"), arr(T + "attention.output.dense.weight").T, (E, E))
+        put(L + ("attention", "output", "dense", "bias"), arr(T + "attention.output.dense.bias"), (E,))
+        put(L + ("layer_scale1", "lambda1"), arr(T + "layer_scale1.lambda1"), (E,))
+        put(L + ("layer_scale2", "lambda1"), arr(T + "layer_scale2.lambda1"), (E,))
+        put(L + ("mlp", "fc1", "kernel"), arr(T + "mlp.fc1.weight").T, (E, g.enc_mlp))
+        put(L + ("mlp", "fc1", "bias"), arr(T + "mlp.fc1.bias"), (g.enc_mlp,))
+        put(L + ("mlp", "fc2", "kernel"), arr(T + "mlp.fc2.weight").T, (g.enc_mlp, E))
+        put(L + ("mlp", "fc2", "bias"), arr(T + "mlp.fc2.bias"), (E,))
+    put(("layernorm", "scale"), arr("layernorm.weight"), (E,))
+    put(("layernorm", "bias"), arr("layernorm.bias"), (E,))
+    assert set(out) == {shared_name(p) for p in shapes}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ whole checkpoint directories
+def convert_checkpoint(src_dir: str, dst_dir: str, step: int, ema: Optional[float] = 0.999,
+                       tree: Optional[Mapping] = None) -> str:
+    """Reference run directory -> a directory `HyperVLA.load_pretrained` reads.
+
+    Parameters come from `tree` when given (a host-side flax tree), else from ``<src_dir>/<step>/EMA_params.pkl``.
+    ``config.json`` and ``dataset_statistics.json`` are copied as they are (`hypervla/model.py:260-284`)."""
+    with open(os.path.join(src_dir, "config.json")) as f:
+        config = json.load(f)
+    if "action_head_kwargs" not in config["base_net_kwargs"]:            # hypervla/model.py:157-163
+        config["base_net_kwargs"]["action_head_kwargs"] = dict(
+            token_per_horizon=False, squash_continuous_action=True, clip_target=False, max_action=5.0)
+    g = geometry_from_config(config)
+    if tree is None:
+        if ema is None:
+            raise ValueError("pass the restored parameter tree, or ema=<coefficient> to read EMA_params.pkl")
+        tree = load_ema_pickle(os.path.join(src_dir, str(step), "EMA_params.pkl"), ema)
+    params = params_from_tree(tree, g)
+    os.makedirs(dst_dir, exist_ok=True)
+    out = os.path.join(dst_dir, f"params_{step}.npz")
+    np.savez(out, **params)
+    for name in ("config.json", "dataset_statistics.json"):
+        sp = os.path.join(src_dir, name)
+        if os.path.exists(sp) and os.path.abspath(src_dir) != os.path.abspath(dst_dir):
+            shutil.copyfile(sp, os.path.join(dst_dir, name))
+    return out

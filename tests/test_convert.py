@@ -1,0 +1,154 @@
+"""Checkpoint conversion: jax-free EMA pickle reader, flax tree -> flat names, HF torch DINOv2
+state_dict -> shared leaves, position-table baking."""
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from hypervla import synthetic as syn
+from hypervla.config import MID, TINY, default_config, encoder_leaves, generated_leaves, hypernet_param_shapes, shared_name
+from hypervla import convert as cv
+
+
+def _nest(flat):
+    tree = {}
+    for k, v in flat.items():
+        node = tree
+        parts = k.split("/")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = v
+    return tree
+
+
+class _FakeJaxArray:
+    """Pickles exactly like jax's ArrayImpl.__reduce__: (jax._src.array._reconstruct_array, (fun, args, state, aval))."""
+
+    def __init__(self, value):
+        self.value = np.asarray(value)
+
+    def __reduce__(self):
+        fun, args, arr_state = self.value.__reduce__()
+        return sys.modules["jax._src.array"]._reconstruct_array, (fun, args, arr_state, {"weak_type": False, "named_shape": {}})
+
+
+@pytest.fixture
+def fake_jax():
+    """A module named like jax's so that pickle.dumps emits the real GLOBAL opcode; removed before loading."""
+    names = ["jax", "jax._src", "jax._src.array"]
+    saved = {n: sys.modules.get(n) for n in names}
+    mods = {n: types.ModuleType(n) for n in names}
+
+    def _reconstruct_array(*a):                      # never called: the reader must not need it
+        raise AssertionError("the jax-free reader called into jax")
+
+    _reconstruct_array.__module__, _reconstruct_array.__qualname__ = "jax._src.array", "_reconstruct_array"
+    mods["jax._src.array"]._reconstruct_array = _reconstruct_array
+    sys.modules.update(mods)
+    yield
+    for n in names:
+        if saved[n] is None:
+            sys.modules.pop(n, None)
+        else:
+            sys.modules[n] = saved[n]
+
+
+def test_ema_pickle_without_jax(fake_jax, tmp_path):
+    g = TINY
+    P = syn.synthetic_params(g)
+    tree = _nest({k: _FakeJaxArray(v) for k, v in P.items()})
+    blob = pickle.dumps({"EMA_0.999": tree})
+    assert b"_reconstruct_array" in blob and b"jax._src.array" in blob
+    for n in ("jax", "jax._src", "jax._src.array"):
+        sys.modules.pop(n, None)                     # the reading process has no jax at all
+    (tmp_path / "7").mkdir()
+    (tmp_path / "7" / "EMA_params.pkl").write_bytes(blob)
+    got = cv.params_from_tree(cv.load_ema_pickle(str(tmp_path / "7" / "EMA_params.pkl"), 0.999), g)
+    assert set(got) == set(P)
+    for k in P:
+        np.testing.assert_array_equal(got[k], P[k])
+    with pytest.raises(KeyError):
+        cv.load_ema_pickle(str(tmp_path / "7" / "EMA_params.pkl"), 0.99)
+
+
+def test_convert_checkpoint_directory_round_trip(fake_jax, tmp_path):
+    import json
+    from hypervla.model import HyperVLA
+    g = TINY
+    P = syn.synthetic_params(g)
+    src, dst = tmp_path / "run", tmp_path / "out"
+    (src / "100").mkdir(parents=True)
+    (src / "config.json").write_text(json.dumps(default_config(g)))
+    stats = syn.synthetic_dataset_statistics(g)
+    (src / "dataset_statistics.json").write_text(json.dumps(
+        {k: {kk: {n: np.asarray(a).tolist() for n, a in vv.items()} for kk, vv in v.items()} for k, v in stats.items()}))
+    (src / "100" / "EMA_params.pkl").write_bytes(pickle.dumps({"EMA_0.999": _nest({k: _FakeJaxArray(v) for k, v in P.items()})}))
+    for n in ("jax", "jax._src", "jax._src.array"):
+        sys.modules.pop(n, None)
+    out = cv.convert_checkpoint(str(src), str(dst), 100, ema=0.999)
+    with np.load(out) as z:
+        assert set(z.files) == set(P)
+        np.testing.assert_array_equal(z["task_token_projection/kernel"], P["task_token_projection/kernel"])
+    assert (dst / "config.json").exists() and (dst / "dataset_statistics.json").exists()
+
+
+def test_tree_errors_name_the_problem():
+    g = TINY
+    P = syn.synthetic_params(g)
+    bad = dict(P)
+    bad.pop("layer_pos_embedding")
+    with pytest.raises(KeyError, match="missing"):
+        cv.params_from_tree(_nest(bad), g)
+    extra = dict(P, **{"language_encoder/kernel": np.zeros(3, np.float32)})
+    with pytest.raises(ValueError, match="outside the built path"):
+        cv.params_from_tree(_nest(extra), g)
+    wrong = dict(P, **{"task_token_projection/bias": np.zeros(3, np.float32)})
+    with pytest.raises(ValueError, match="task_token_projection/bias"):
+        cv.params_from_tree(_nest(wrong), g)
+    np.testing.assert_array_equal(cv.params_from_tree({"params": _nest(P)}, g)["layer_pos_embedding"], P["layer_pos_embedding"])
+
+
+def test_position_table_baking_properties():
+    """Bicubic (Keys a = -0.5) resize of the n x n table to the run-time grid with scale (grid + 0.1) / n."""
+    rng = np.random.default_rng(0)
+    n, grid, E = 37, 16, 8
+    table = rng.standard_normal((1, 1 + n * n, E)).astype(np.float32)
+    out = cv.bake_position_embeddings(table, grid)
+    assert out.shape == (1, 1 + grid * grid, E) and out.dtype == np.float32
+    np.testing.assert_array_equal(out[:, 0], table[:, 0])                          # class row untouched
+    np.testing.assert_array_equal(cv.bake_position_embeddings(table, n), table)      # same grid: returned as is
+    w = cv._scale_and_translate_weights(n, grid, np.float32((grid + 0.1) / n))
+    np.testing.assert_allclose(w.sum(0), 1.0, atol=1e-6)                           # every output is an affine combination
+    assert (np.count_nonzero(w, axis=0) <= 4).all()                                # 4-tap cubic
+    # cubic convolution reproduces polynomials of degree <= 2 away from the borders: resample f(y, x) = 2 + 3y - x
+    yy, xx = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), indexing="ij")
+    lin = (2 + 3 * yy - xx).reshape(1, n * n, 1)
+    got = cv.bake_position_embeddings(np.concatenate([np.zeros((1, 1, 1), np.float32), lin], 1), grid)[0, 1:, 0].reshape(grid, grid)
+    pos = (np.arange(grid, dtype=np.float64) + 0.5) * n / (grid + 0.1) - 0.5
+    want = 2 + 3 * pos[:, None] - pos[None, :]
+    inner = (pos >= 1) & (pos <= n - 2)
+    np.testing.assert_allclose(got[np.ix_(inner, inner)], want[np.ix_(inner, inner)], rtol=0, atol=2e-4)
+    # constant tables stay constant everywhere (weights renormalised at the border)
+    const = cv.bake_position_embeddings(np.full((1, 1 + n * n, 2), 0.25, np.float32), grid)
+    np.testing.assert_allclose(const, 0.25, atol=1e-6)
+
+
+def test_hf_state_dict_round_trip():
+    """build the torch Dinov2Model from the checkpoint's shared leaves (oracle), read its state_dict back."""
+    torch = pytest.importorskip("torch")
+    pytest.importorskip("transformers")
+    from oracle import hvla_ref_torch as ot
+    g = MID
+    P = syn.synthetic_params(g)
+    model = ot.build_hf_dinov2(P, g, dict(encoder_leaves(g)))
+    got = cv.dinov2_from_hf_state_dict(model.state_dict(), g)
+    for path, shape in encoder_leaves(g):
+        k = shared_name(path)
+        np.testing.assert_array_equal(got[k], P[k].reshape(-1), err_msg=k)
+    # a 3x3 source table is baked to the geometry's grid on the way
+    sd = dict(model.state_dict())
+    sd["embeddings.position_embeddings"] = torch.randn(1, 1 + 9, g.enc_dim)
+    baked = cv.dinov2_from_hf_state_dict(sd, g)[shared_name(("embeddings", "position_embeddings"))]
+    assert baked.size == (g.patches + 1) * g.enc_dim
