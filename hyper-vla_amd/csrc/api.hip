@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "layout.h"
+#include "t5.h"
 #include "train.h"
 
 using namespace hvla;
@@ -74,6 +75,12 @@ struct hvla_ctx {
   // workspaces (sized for cfg.max_batch)
   DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, tokens, flags;
   Profiler prof;
+  // optional frozen T5 instruction encoder (hvla_t5_load)
+  bool t5_loaded = false;
+  T5Dims t5d{};
+  T5Weights t5w{};
+  DevBuf t5_f32, t5_work;
+  int t5_max_batch = 0;
 };
 
 #define FAIL(ctx, code, ...)                       \
@@ -564,6 +571,104 @@ int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_tr
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const TrainLayout L = make_train_layout(ctx->g);
   HIPCHK(ctx, train_apply(L, to_tb(buf), to_hp(hy), hy->train_encoder != 0, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+// bucket of relative position rel = key - query, bidirectional (transformers `_relative_position_bucket`; the log is
+// evaluated in float32 as both the torch and the flax model do)
+static int t5_bucket(int rel, int buckets, int max_distance) {
+  const int nb = buckets / 2, max_exact = nb / 2;
+  int out = rel > 0 ? nb : 0;
+  const int n = rel < 0 ? -rel : rel;
+  if (n < max_exact) return out + n;
+  const float v = logf((float)n / (float)max_exact) / (float)log((double)max_distance / (double)max_exact) * (float)(nb - max_exact);
+  int large = max_exact + (int)v;
+  if (large > nb - 1) large = nb - 1;
+  return out + large;
+}
+
+int hvla_t5_load(hvla_ctx* ctx, const hvla_t5_config* c, const hvla_tensor_desc* t, int32_t n) {
+  if (!ctx || !c) return HVLA_E_STATE;
+  if (c->layers < 1 || c->layers > 24 || c->heads < 1 || c->d_model < 1 || c->d_kv < 1 || c->d_ff < 1 || c->vocab < 1 ||
+      c->buckets < 4 || c->buckets % 2 || c->max_tokens < 1 || c->max_batch < 1)
+    FAIL(ctx, HVLA_E_SHAPE, "bad T5 configuration");
+  if (c->d_model != ctx->g.lang_dim) FAIL(ctx, HVLA_E_SHAPE, "T5 d_model %d != lang_dim %d of the hypernetwork", c->d_model, ctx->g.lang_dim);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::map<std::string, const hvla_tensor_desc*> m;
+  for (int i = 0; i < n; ++i) {
+    if (!t[i].name || !t[i].data) FAIL(ctx, HVLA_E_WEIGHTS, "tensor %d has null name/data", i);
+    std::string nm = t[i].name;
+    if (nm.rfind("hf_model/", 0) == 0) nm = nm.substr(9);          // the reference nests the HF module under `hf_model`
+    m[nm] = &t[i];
+  }
+  const int D = c->d_model, I = c->heads * c->d_kv, F = c->d_ff, TM = c->max_tokens;
+  std::vector<float> host;
+  std::vector<std::pair<const float**, size_t>> fix;
+  std::string bad;
+  auto push = [&](const float** slot, const std::string& name, int64_t numel) {
+    auto it = m.find(name);
+    if (it == m.end() || it->second->numel != numel) {
+      if (bad.empty()) bad = name + (it == m.end() ? " (absent)" : " (wrong size)");
+      return;
+    }
+    const size_t off = (host.size() + 3) / 4 * 4;
+    host.resize(off + numel);
+    memcpy(host.data() + off, it->second->data, (size_t)numel * 4);
+    fix.emplace_back(slot, off);
+  };
+  T5Weights w{};
+  w.max_tokens = TM;
+  push(&w.shared, "shared/embedding", (int64_t)c->vocab * D);
+  push(&w.final_ln, "encoder/final_layer_norm/weight", D);
+  for (int l = 0; l < c->layers; ++l) {
+    const std::string b = "encoder/block/" + std::to_string(l) + "/layer/";
+    T5LayerW& L = w.layer[l];
+    push(&L.ln0, b + "0/layer_norm/weight", D);
+    push(&L.wq, b + "0/SelfAttention/q/kernel", (int64_t)D * I);
+    push(&L.wk, b + "0/SelfAttention/k/kernel", (int64_t)D * I);
+    push(&L.wv, b + "0/SelfAttention/v/kernel", (int64_t)D * I);
+    push(&L.wo, b + "0/SelfAttention/o/kernel", (int64_t)I * D);
+    push(&L.ln1, b + "1/layer_norm/weight", D);
+    push(&L.wi, b + "1/DenseReluDense/wi/kernel", (int64_t)D * F);
+    push(&L.wo2, b + "1/DenseReluDense/wo/kernel", (int64_t)F * D);
+  }
+  // relative-position bias table [heads][2 TM - 1] from the first block's bucket embedding [buckets][heads]
+  {
+    auto it = m.find("encoder/block/0/layer/0/SelfAttention/relative_attention_bias/embedding");
+    if (it == m.end() || it->second->numel != (int64_t)c->buckets * c->heads) {
+      if (bad.empty()) bad = "encoder/block/0/layer/0/SelfAttention/relative_attention_bias/embedding";
+    } else {
+      const float* emb = it->second->data;
+      const size_t off = (host.size() + 3) / 4 * 4;
+      host.resize(off + (size_t)c->heads * (2 * TM - 1));
+      for (int h = 0; h < c->heads; ++h)
+        for (int r = -(TM - 1); r <= TM - 1; ++r)
+          host[off + (size_t)h * (2 * TM - 1) + (r + TM - 1)] = emb[(size_t)t5_bucket(r, c->buckets, c->max_distance) * c->heads + h];
+      fix.emplace_back(&w.relbias, off);
+    }
+  }
+  if (!bad.empty()) FAIL(ctx, HVLA_E_WEIGHTS, "T5 tensor %s", bad.c_str());
+  HIPCHK(ctx, ctx->t5_f32.alloc(host.size() * 4));
+  HIPCHK(ctx, hipMemcpy(ctx->t5_f32.p, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+  for (auto& f : fix) *f.first = ctx->t5_f32.as<float>() + f.second;
+  ctx->t5d = T5Dims{c->vocab, D, c->d_kv, c->heads, F, c->layers, c->buckets, c->max_distance, c->eps};
+  ctx->t5w = w;
+  ctx->t5_max_batch = c->max_batch;
+  HIPCHK(ctx, ctx->t5_work.alloc(t5_workspace_floats(ctx->t5d, c->max_batch, TM) * 4));
+  ctx->t5_loaded = true;
+  return HVLA_OK;
+}
+
+int hvla_t5_encode(hvla_ctx* ctx, const int64_t* input_ids, const int64_t* attention_mask, float* token_embedding, int32_t B,
+                   int32_t T, void* stream) {
+  if (!ctx) return HVLA_E_STATE;
+  if (!ctx->t5_loaded) FAIL(ctx, HVLA_E_STATE, "hvla_t5_load has not been called");
+  if (B < 1 || B > ctx->t5_max_batch || T < 1 || T > ctx->t5w.max_tokens)
+    FAIL(ctx, HVLA_E_SHAPE, "batch %d / tokens %d outside [1, %d] x [1, %d]", B, T, ctx->t5_max_batch, ctx->t5w.max_tokens);
+  if (!input_ids || !attention_mask || !token_embedding) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, t5_encode(ctx->t5d, ctx->t5w, ctx->t5_work.as<float>(), input_ids, attention_mask, token_embedding, B, T,
+                        reinterpret_cast<hipStream_t>(stream)));
   return HVLA_OK;
 }
 

@@ -7,6 +7,22 @@
 
 namespace hvla {
 
+// generic batched f32 GEMM on the matrix cores (split-bf16, f32-class accuracy; train.hip):
+//   C[b0,b1] (+)= alpha * op(A)[b0,b1] * op(B)[b0,b1] (+ bias[b0][n]),  batch = blockIdx.z = b0 * nb1 + b1
+struct BG {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;          // nullable, indexed [n], batch stride sBias0
+  int M, N, K, lda, ldb, ldc;
+  long sA0, sA1, sB0, sB1, sC0, sC1, sBias0;
+  int nb1;                    // batch = blockIdx.z = b0 * nb1 + b1
+  float alpha;
+  int accumulate;             // 0 store, 1 C += (one writer per element), 2 atomic C += (batches share C)
+  int ksplit = 1;             // > 1: K is cut into ksplit chunks over blockIdx.z, reduced with atomics (accumulate != 0)
+};
+void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0);
+
 // flat layout of the trainable hypernetwork parameters (float32 elements)
 // `total` = the hypernetwork's own parameters; the shared DINOv2 leaves follow at [total, total + enc_total) when the
 // image encoder is trained too (`fine_tune_pretrained_image_encoder=True`), in hypervla.config.encoder_leaves order.

@@ -29,18 +29,6 @@ namespace hvla {
 // ------------------------------------------------------------------------------------------------
 // generic batched GEMM  C[b0,b1] (+)= alpha * op(A)[b0,b1] * op(B)[b0,b1] (+ bias[b0][n])
 // ------------------------------------------------------------------------------------------------
-struct BG {
-  const float* A;
-  const float* B;
-  float* C;
-  const float* bias;          // nullable, indexed [n], batch stride sBias0
-  int M, N, K, lda, ldb, ldc;
-  long sA0, sA1, sB0, sB1, sC0, sC1, sBias0;
-  int nb1;                    // batch = blockIdx.z = b0 * nb1 + b1
-  float alpha;
-  int accumulate;             // 0 store, 1 C += (one writer per element), 2 atomic C += (batches share C)
-  int ksplit = 1;             // > 1: K is cut into ksplit chunks over blockIdx.z, reduced with atomics (accumulate != 0)
-};
 
 // 64x64 output tile per workgroup, 4 waves x (32x32) on the exact-f32 matrix instruction
 // v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, guide §3): lane l supplies A[i = l & 31][k = l >> 5] and
@@ -274,7 +262,7 @@ static bool train_gemm_exact() {
   return v != 0;
 }
 
-static void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
+void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
   const bool exact = train_gemm_exact();
   static const long min128 = [] { const char* e = getenv("HVLA_MIN128"); return e ? atol(e) : 0L; }();
   int T = !exact && g.M >= 96 && g.N >= 96 ? 128 : 64;

@@ -18,7 +18,8 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_generate", "hvla_weights_free", "hvla_weights_batch", "hvla_weights_export",
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
-           "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden"]
+           "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
+           "hvla_t5_encode"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy"]
 
 
@@ -33,6 +34,11 @@ class hvla_config(C.Structure):
 
 class hvla_tensor_desc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class hvla_t5_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab", "d_model", "d_kv", "heads", "d_ff", "layers", "buckets", "max_distance")] + \
+               [("eps", C.c_float), ("max_tokens", C.c_int32), ("max_batch", C.c_int32)]
 
 
 class hvla_train_buffers(C.Structure):
@@ -85,6 +91,10 @@ def load_library():
     lib.hvla_encode.restype = C.c_int
     lib.hvla_encode_hidden.argtypes = [vp, vp, vp, i32, vp]
     lib.hvla_encode_hidden.restype = C.c_int
+    lib.hvla_t5_load.argtypes = [vp, C.POINTER(hvla_t5_config), C.POINTER(hvla_tensor_desc), i32]
+    lib.hvla_t5_load.restype = C.c_int
+    lib.hvla_t5_encode.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    lib.hvla_t5_encode.restype = C.c_int
     lib.hvla_policy.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.hvla_policy.restype = C.c_int
     lib.hvla_step.argtypes = [vp, vp, vp, vp, vp, i32, vp]
@@ -165,6 +175,20 @@ class Context:
             keep.append(a)
             descs[i] = hvla_tensor_desc(k.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size)
         self._check(self.lib.hvla_load_weights(self.h, descs, len(params)), "hvla_load_weights")
+
+    def t5_load(self, t, params: Dict[str, np.ndarray], max_tokens: int, max_batch: int):
+        keep = []
+        descs = (hvla_tensor_desc * len(params))()
+        for i, (k, v) in enumerate(params.items()):
+            a = np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+            keep.append(a)
+            descs[i] = hvla_tensor_desc(k.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size)
+        cfg = hvla_t5_config(t.vocab, t.d_model, t.d_kv, t.heads, t.d_ff, t.layers, t.buckets, t.max_distance, t.eps,
+                             max_tokens, max_batch)
+        self._check(self.lib.hvla_t5_load(self.h, C.byref(cfg), descs, len(params)), "hvla_t5_load")
+
+    def t5_encode(self, ids_ptr, mask_ptr, out_ptr, B, T, stream=0):
+        self._check(self.lib.hvla_t5_encode(self.h, ids_ptr, mask_ptr, out_ptr, B, T, C.c_void_p(stream)), "hvla_t5_encode")
 
     def selftest(self, stream: int = 0):
         self._check(self.lib.hvla_selftest(self.h, C.c_void_p(stream)), "hvla_selftest")

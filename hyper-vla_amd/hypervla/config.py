@@ -90,6 +90,47 @@ TINY = Geometry(image_size=56, patch=14, enc_dim=32, enc_layers=2, enc_heads=2, 
 # Generated-leaf metadata  (reference: init_base_net, hypervla/model.py:370-515)
 # --------------------------------------------------------------------------------------
 @dataclass(frozen=True)
+class T5Geometry:
+    """Frozen instruction encoder (``LanguageTokenizer('t5-base')``, data/utils/language_tokenizer.py:9-28;
+    octo/model/components/tokenizers.py:186-211): HF ``T5Config`` fields of "t5-base"."""
+    vocab: int = 32128
+    d_model: int = 768
+    d_kv: int = 64
+    heads: int = 12
+    d_ff: int = 3072
+    layers: int = 12
+    buckets: int = 32            # relative_attention_num_buckets
+    max_distance: int = 128      # relative_attention_max_distance
+    eps: float = 1e-6
+
+    @property
+    def inner(self) -> int:
+        return self.heads * self.d_kv
+
+
+T5_BASE = T5Geometry()
+T5_TINY = T5Geometry(vocab=300, d_model=32, d_kv=8, heads=2, d_ff=64, layers=2)      # pairs with TINY (lang_dim 32)
+T5_MID = T5Geometry(vocab=1000, d_model=768, d_kv=64, heads=12, d_ff=3072, layers=2)  # full widths, 2 layers (tests)
+
+
+def t5_param_shapes(t: T5Geometry) -> Dict[str, Tuple[int, ...]]:
+    """FlaxT5EncoderModel parameter tree, '/'-joined (kernels are [in, out])."""
+    s: Dict[str, Tuple[int, ...]] = {"shared/embedding": (t.vocab, t.d_model)}
+    for i in range(t.layers):
+        b = f"encoder/block/{i}/layer/"
+        for nm in ("q", "k", "v"):
+            s[b + f"0/SelfAttention/{nm}/kernel"] = (t.d_model, t.inner)
+        s[b + "0/SelfAttention/o/kernel"] = (t.inner, t.d_model)
+        s[b + "0/layer_norm/weight"] = (t.d_model,)
+        s[b + "1/DenseReluDense/wi/kernel"] = (t.d_model, t.d_ff)
+        s[b + "1/DenseReluDense/wo/kernel"] = (t.d_ff, t.d_model)
+        s[b + "1/layer_norm/weight"] = (t.d_model,)
+    s["encoder/block/0/layer/0/SelfAttention/relative_attention_bias/embedding"] = (t.buckets, t.heads)
+    s["encoder/final_layer_norm/weight"] = (t.d_model,)
+    return s
+
+
+@dataclass(frozen=True)
 class Leaf:
     path: Tuple[str, ...]       # base-net pytree path
     shape: Tuple[int, ...]

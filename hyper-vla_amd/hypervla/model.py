@@ -169,6 +169,35 @@ class HyperVLA:
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(np.asarray(a))).to(device=self.device, dtype=dtype).contiguous()
 
+    # ------------------------------------------------------------------ frozen instruction encoder (optional)
+    def load_language_encoder(self, t5_params: Dict[str, np.ndarray], t5_geometry=None, max_batch: Optional[int] = None):
+        """Put the frozen T5 encoder of `LanguageTokenizer('t5-base')` on the device
+        (data/utils/language_tokenizer.py:9-28).  `t5_params`: FlaxT5EncoderModel tree flattened with '/'."""
+        from .config import T5_BASE
+        t = T5_BASE if t5_geometry is None else t5_geometry
+        if t.d_model != self.geometry.lang_dim:
+            raise ValueError(f"T5 d_model {t.d_model} != lang_dim {self.geometry.lang_dim}")
+        self._ctx.t5_load(t, t5_params, self.geometry.lang_tokens, max_batch or self.max_batch)
+        self.language_encoder = t
+        return self
+
+    def encode_instructions(self, tokens: Dict) -> Dict:
+        """`token_to_embedding` (data/utils/language_tokenizer.py:24-28) on the device: {"input_ids", "attention_mask"}
+        i64 [B, T] -> the same dict plus "token_embedding" f32 [B, T, lang_dim] (a CUDA tensor)."""
+        torch = _torch()
+        if getattr(self, "language_encoder", None) is None:
+            raise RuntimeError("no language encoder loaded: call load_language_encoder(t5_params) first")
+        ids = self._dev(tokens["input_ids"], torch.int64)
+        mask = self._dev(tokens["attention_mask"], torch.int64)
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError(f"input_ids {tuple(ids.shape)} / attention_mask {tuple(mask.shape)} must be [B, T]")
+        B, T = ids.shape
+        emb = torch.empty(B, T, self.geometry.lang_dim, dtype=torch.float32, device=self.device)
+        self._ctx.t5_encode(ids.data_ptr(), mask.data_ptr(), emb.data_ptr(), B, T, self._stream())
+        out = dict(tokens)
+        out["token_embedding"] = emb
+        return out
+
     # ------------------------------------------------------------------ the hot path
     def create_tasks(self, goals=None, instruction_dict: Dict = None, initial_state: Dict = None):
         """hypervla/model.py:35-83.  Returns (base_params handle, tasks dict, intermediates)."""
@@ -177,6 +206,8 @@ class HyperVLA:
             raise ValueError("the built path is language + initial-image conditioned: instruction_dict and "
                              "initial_state are required (use_initial_image=True, README.md:42)")
         li = instruction_dict["language_instruction"]
+        if "token_embedding" not in li and getattr(self, "language_encoder", None) is not None:
+            li = self.encode_instructions(li)                      # scripts/train.py:407-415 does this inside the step
         g = self.geometry
         B = int(np.shape(li["input_ids"])[0])
         tok = self._dev(li["token_embedding"], torch.float32)

@@ -12,8 +12,8 @@ from typing import Dict, Tuple
 
 import numpy as np
 
-from .config import (FULL, Geometry, encoder_leaves, generated_leaves, hypernet_param_shapes,
-                     shared_name)
+from .config import (FULL, T5_BASE, Geometry, T5Geometry, encoder_leaves, generated_leaves, hypernet_param_shapes,
+                     shared_name, t5_param_shapes)
 
 SEED_IMAGES, SEED_TOKENS, SEED_CLS, SEED_STATS, SEED_WEIGHTS = 1000, 2000, 3000, 4000, 5000
 
@@ -158,3 +158,38 @@ def synthetic_action_batch(batch: int, g: Geometry = FULL, rank: int = 0) -> Dic
     apm = rng.uniform(size=a.shape) > 0.15
     tpm = rng.uniform(size=(batch, 1)) > 0.1
     return {"action": a, "action_pad_mask": apm, "timestep_pad_mask": tpm}
+
+
+def synthetic_t5_params(t: T5Geometry = T5_BASE, seed: int = 7000) -> Dict[str, np.ndarray]:
+    """Random T5 encoder weights under the FlaxT5EncoderModel names (no checkpoint exists offline).  Scales follow
+    T5's own initialisation closely enough that activations stay O(1) through 12 layers."""
+    rng = _rng(seed)
+    p: Dict[str, np.ndarray] = {}
+    for k, shp in t5_param_shapes(t).items():
+        if k.endswith("layer_norm/weight"):
+            v = 1.0 + 0.05 * rng.standard_normal(shp)
+        elif k.endswith("relative_attention_bias/embedding"):
+            v = 0.5 * rng.standard_normal(shp)
+        elif k == "shared/embedding":
+            v = rng.standard_normal(shp)
+        elif k.endswith("q/kernel"):
+            v = rng.standard_normal(shp) * (t.d_model * t.d_kv) ** -0.5
+        elif k.endswith("wo/kernel"):
+            v = rng.standard_normal(shp) * t.d_ff ** -0.5
+        elif k.endswith("o/kernel"):
+            v = rng.standard_normal(shp) * t.inner ** -0.5
+        else:
+            v = rng.standard_normal(shp) * t.d_model ** -0.5
+        p[k] = v.astype(np.float32)
+    return p
+
+
+def synthetic_token_ids(batch: int, t: T5Geometry = T5_BASE, tokens: int = 32, rank: int = 0) -> Dict:
+    """input_ids / attention_mask as HFTokenizer(max_length=32, padding="max_length") returns them: ids, EOS (1), pads (0)."""
+    rng = _rng(SEED_TOKENS + 500 + rank)
+    n = rng.integers(3, min(20, tokens) + 1, size=batch)
+    ids = rng.integers(2, t.vocab, size=(batch, tokens)).astype(np.int64)
+    mask = (np.arange(tokens)[None, :] < n[:, None]).astype(np.int64)
+    ids = ids * mask
+    ids[np.arange(batch), n - 1] = 1
+    return {"input_ids": ids, "attention_mask": mask}

@@ -178,6 +178,22 @@ int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* t
                     const uint8_t* action_mask, int32_t B, const hvla_train_hyper* hyper, void* stream);
 int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_train_hyper* hyper, void* stream);
 
+/* Replaces: the frozen instruction encoder `LanguageTokenizer('t5-base')` that produces
+ * task["language_instruction"]["token_embedding"] (octo/model/components/tokenizers.py:186-211;
+ * data/utils/language_tokenizer.py:9-28; scripts/train.py:407-415 runs it inside every training step):
+ * FlaxT5EncoderModel(config).module(input_ids, attention_mask).last_hidden_state.  Optional: load once, then
+ * input_ids / attention_mask i64 [B, T] (device) -> token_embedding f32 [B, T, d_model] (device), ready for
+ * hvla_generate.  Tensors are named as in the flax tree ('/'-joined, kernels [in, out]; an `hf_model/` prefix is
+ * accepted); d_model must equal the hypernetwork's lang_dim.  Tokenisation (SentencePiece) stays on the host.      */
+typedef struct hvla_t5_config {
+  int32_t vocab, d_model, d_kv, heads, d_ff, layers, buckets, max_distance;
+  float eps;
+  int32_t max_tokens, max_batch;
+} hvla_t5_config;
+int hvla_t5_load(hvla_ctx* ctx, const hvla_t5_config* cfg, const hvla_tensor_desc* tensors, int32_t n);
+int hvla_t5_encode(hvla_ctx* ctx, const int64_t* input_ids, const int64_t* attention_mask, float* token_embedding,
+                   int32_t B, int32_t T, void* stream);
+
 /* Live per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  *   mode 0: off (default);  1: only the dominant kernel (encoder fc1 GEMM);  2: every category.
  * hvla_profile_read synchronises the recorded events, adds their durations per category into

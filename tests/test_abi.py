@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "hvla.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(hvla_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(hvla_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree():

@@ -301,3 +301,34 @@ def test_initial_image_hidden_state(mid):
     w_ref, _, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=st_ref)
     th_dev, th_ref = w_dev.export()[0], w_ref.export()[0]
     assert float((th_dev - th_ref).abs().max()) <= 5e-3
+
+
+def test_t5_instruction_encoder(full):
+    """hvla_t5_encode = FlaxT5EncoderModel(...).last_hidden_state: full-width 2-layer T5 (768 / 12 heads / 3072) against
+    the float64 restatement (itself checked against transformers' torch T5 in tests/test_oracle_properties.py), padded
+    and unpadded sequences; then create_tasks straight from token ids."""
+    from hypervla import synthetic as syn
+    from hypervla.config import T5_MID
+    from oracle import hvla_ref_np as onp
+    m, g, B = full["model"], full["g"], full["B"]
+    tp = syn.synthetic_t5_params(T5_MID)
+    m.load_language_encoder(tp, T5_MID)
+    tok = syn.synthetic_token_ids(B, T5_MID, g.lang_tokens)
+    tok["attention_mask"][0] = 1                                       # one sequence without padding
+    got = m.encode_instructions(tok)["token_embedding"].cpu().numpy().astype(np.float64)
+    ref = onp.t5_encoder(tp, T5_MID, tok["input_ids"], tok["attention_mask"])
+    keep = tok["attention_mask"].astype(bool)
+    assert got.shape == ref.shape == (B, g.lang_tokens, g.lang_dim)
+    assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+    # shorter T than max_tokens goes through the same relative-position table
+    t8 = {k: v[:, :8].copy() for k, v in tok.items()}
+    t8["attention_mask"][:] = 1
+    got8 = m.encode_instructions(t8)["token_embedding"].cpu().numpy()
+    np.testing.assert_allclose(got8, onp.t5_encoder(tp, T5_MID, t8["input_ids"], t8["attention_mask"]), atol=3e-4)
+    # create_tasks from ids only == create_tasks from the oracle's embedding
+    ins_ids = {"language_instruction": dict(tok)}
+    ins_ref = {"language_instruction": dict(tok, token_embedding=ref.astype(np.float32))}
+    w_a, _, _ = m.create_tasks(instruction_dict=ins_ids, initial_state=full["st"])
+    w_b, _, _ = m.create_tasks(instruction_dict=ins_ref, initial_state=full["st"])
+    assert float((w_a.export()[0] - w_b.export()[0]).abs().max()) <= 2e-3
+    assert keep.any()

@@ -1,5 +1,6 @@
 """CPU: invariants the reference *code* guarantees (SURVEY.md §8c pin 3), checked on the oracle."""
 import numpy as np
+import pytest
 
 from hypervla import synthetic as syn
 from hypervla.config import TINY, encoder_leaves, generated_leaves
@@ -128,3 +129,44 @@ def test_mix_loss_numpy_vs_torch_and_gradient_oracle():
         vals.append(onp.mix_loss(G, a2[..., :6], l2, batch["action"], batch["timestep_pad_mask"], batch["action_pad_mask"])[1])
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - float(grads[key][idx])) <= 1e-6 * max(1.0, abs(fd))
+
+
+def test_t5_restatement_matches_transformers_torch_t5():
+    """The float64 T5 encoder restatement against transformers' own torch T5EncoderModel (same architecture as the
+    FlaxT5EncoderModel the reference calls) on random weights, incl. padding and the relative-position buckets."""
+    torch = pytest.importorskip("torch")
+    tr = pytest.importorskip("transformers")
+    from hypervla import synthetic as syn
+    from hypervla.config import T5_TINY, T5Geometry
+    from oracle import hvla_ref_np as onp
+    for t in (T5_TINY, T5Geometry(vocab=500, d_model=96, d_kv=16, heads=6, d_ff=160, layers=3)):
+        cfg = tr.T5Config(vocab_size=t.vocab, d_model=t.d_model, d_kv=t.d_kv, d_ff=t.d_ff, num_layers=t.layers,
+                          num_heads=t.heads, relative_attention_num_buckets=t.buckets,
+                          relative_attention_max_distance=t.max_distance, feed_forward_proj="relu",
+                          layer_norm_epsilon=t.eps, dropout_rate=0.0)
+        m = tr.T5EncoderModel(cfg).eval().double()
+        tp = syn.synthetic_t5_params(t)
+        sd = {"shared.weight": tp["shared/embedding"], "encoder.embed_tokens.weight": tp["shared/embedding"],
+              "encoder.final_layer_norm.weight": tp["encoder/final_layer_norm/weight"],
+              "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight":
+                  tp["encoder/block/0/layer/0/SelfAttention/relative_attention_bias/embedding"]}
+        for i in range(t.layers):
+            b, T = f"encoder/block/{i}/layer/", f"encoder.block.{i}.layer."
+            for nm in "qkvo":
+                sd[T + f"0.SelfAttention.{nm}.weight"] = tp[b + f"0/SelfAttention/{nm}/kernel"].T
+            sd[T + "0.layer_norm.weight"] = tp[b + "0/layer_norm/weight"]
+            sd[T + "1.DenseReluDense.wi.weight"] = tp[b + "1/DenseReluDense/wi/kernel"].T
+            sd[T + "1.DenseReluDense.wo.weight"] = tp[b + "1/DenseReluDense/wo/kernel"].T
+            sd[T + "1.layer_norm.weight"] = tp[b + "1/layer_norm/weight"]
+        m.load_state_dict({k: torch.as_tensor(np.ascontiguousarray(v)).double() for k, v in sd.items()}, strict=True)
+        tok = syn.synthetic_token_ids(3, t)
+        with torch.no_grad():
+            ref = m(input_ids=torch.as_tensor(tok["input_ids"]),
+                    attention_mask=torch.as_tensor(tok["attention_mask"])).last_hidden_state.numpy()
+        got = onp.t5_encoder(tp, t, tok["input_ids"], tok["attention_mask"])
+        assert np.abs(got - ref).max() <= 1e-5
+        blk = m.encoder.block[0].layer[0].SelfAttention
+        for T_ in (8, 32, 77, 200):
+            rp = torch.arange(T_)[None, :] - torch.arange(T_)[:, None]
+            np.testing.assert_array_equal(blk._relative_position_bucket(rp, True, t.buckets, t.max_distance).numpy(),
+                                          onp.t5_relative_buckets(T_, t.buckets, t.max_distance))
