@@ -200,6 +200,37 @@ def dinov2_from_hf_state_dict(sd: Mapping[str, Any], g: Geometry) -> Dict[str, n
     return out
 
 
+# ------------------------------------------------------------------------------------------------ HF torch T5 -> flax names
+def t5_from_hf_state_dict(sd: Mapping[str, Any], t) -> Dict[str, np.ndarray]:
+    """``T5EncoderModel.state_dict()`` ("t5-base", torch) -> the FlaxT5EncoderModel tree `load_language_encoder` takes
+    ('/'-joined names, Linear weights transposed to [in, out]; octo/utils/train_utils.py:542-568 `hf_weights_loader`)."""
+    from .config import t5_param_shapes
+
+    def arr(name):
+        v = sd[name]
+        v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        return np.asarray(v, np.float32)
+
+    out = {"shared/embedding": arr("shared.weight"), "encoder/final_layer_norm/weight": arr("encoder.final_layer_norm.weight"),
+           "encoder/block/0/layer/0/SelfAttention/relative_attention_bias/embedding":
+               arr("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight")}
+    for i in range(t.layers):
+        b, T = f"encoder/block/{i}/layer/", f"encoder.block.{i}.layer."
+        for nm in "qkvo":
+            out[b + f"0/SelfAttention/{nm}/kernel"] = np.ascontiguousarray(arr(T + f"0.SelfAttention.{nm}.weight").T)
+        out[b + "0/layer_norm/weight"] = arr(T + "0.layer_norm.weight")
+        out[b + "1/DenseReluDense/wi/kernel"] = np.ascontiguousarray(arr(T + "1.DenseReluDense.wi.weight").T)
+        out[b + "1/DenseReluDense/wo/kernel"] = np.ascontiguousarray(arr(T + "1.DenseReluDense.wo.weight").T)
+        out[b + "1/layer_norm/weight"] = arr(T + "1.layer_norm.weight")
+    shapes = t5_param_shapes(t)
+    if set(out) != set(shapes):
+        raise KeyError(sorted(set(out) ^ set(shapes))[:4])
+    for k, shp in shapes.items():
+        if tuple(out[k].shape) != tuple(shp):
+            raise ValueError(f"{k}: {out[k].shape} != {tuple(shp)}")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ whole checkpoint directories
 def convert_checkpoint(src_dir: str, dst_dir: str, step: int, ema: Optional[float] = 0.999,
                        tree: Optional[Mapping] = None) -> str:

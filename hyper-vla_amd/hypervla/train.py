@@ -150,6 +150,8 @@ class FineTuner:
         encoder's patch tokens f32 [B, P, E], or -- with train_encoder -- the uint8 observations [B, (1,) H, W, 3]."""
         torch, m, g = self.torch, self.model, self.g
         li = instruction_dict["language_instruction"]
+        if "token_embedding" not in li:                    # frozen T5 inside the step, as scripts/train.py:407-415
+            li = m.encode_instructions(li)
         tok = m._dev(li["token_embedding"], torch.float32)
         msk = m._dev(li["attention_mask"], torch.int64)
         cls = m._dev(np.asarray(initial_state["patch_embeddings"])[:, 0], torch.float32)

@@ -152,3 +152,16 @@ def test_hf_state_dict_round_trip():
     sd["embeddings.position_embeddings"] = torch.randn(1, 1 + 9, g.enc_dim)
     baked = cv.dinov2_from_hf_state_dict(sd, g)[shared_name(("embeddings", "position_embeddings"))]
     assert baked.size == (g.patches + 1) * g.enc_dim
+
+
+def test_t5_state_dict_names():
+    torch = pytest.importorskip("torch")
+    tr = pytest.importorskip("transformers")
+    from hypervla.config import T5_TINY as t, t5_param_shapes
+    cfg = tr.T5Config(vocab_size=t.vocab, d_model=t.d_model, d_kv=t.d_kv, d_ff=t.d_ff, num_layers=t.layers, num_heads=t.heads,
+                      feed_forward_proj="relu")
+    m = tr.T5EncoderModel(cfg)
+    got = cv.t5_from_hf_state_dict(m.state_dict(), t)
+    assert set(got) == set(t5_param_shapes(t))
+    np.testing.assert_array_equal(got["encoder/block/1/layer/1/DenseReluDense/wi/kernel"],
+                                  m.state_dict()["encoder.block.1.layer.1.DenseReluDense.wi.weight"].numpy().T)
