@@ -75,6 +75,9 @@ struct hvla_ctx {
   // workspaces (sized for cfg.max_batch)
   DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, tokens, flags;
   Profiler prof;
+  // observation preprocessing (hvla_preprocess): span tables of the last (H, W) and scratch
+  int rs_H = 0, rs_W = 0, rs_row_span = 0, rs_col_span = 0;
+  DevBuf rs_tab, rs_rows, rs_img;
   // optional frozen T5 instruction encoder (hvla_t5_load)
   bool t5_loaded = false;
   T5Dims t5d{};
@@ -571,6 +574,43 @@ int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_tr
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const TrainLayout L = make_train_layout(ctx->g);
   HIPCHK(ctx, train_apply(L, to_tb(buf), to_hp(hy), hy->train_encoder != 0, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_preprocess(hvla_ctx* ctx, const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t crop, uint8_t* images,
+                    void* stream) {
+  if (!ctx) return HVLA_E_STATE;
+  if (B < 1 || H < 2 || W < 2 || H > 8192 || W > 8192) FAIL(ctx, HVLA_E_SHAPE, "frames [%d, %d, %d, 3]", B, H, W);
+  if (!frames || !images) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int S = ctx->g.image_size;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (H != ctx->rs_H || W != ctx->rs_W) {                      // new source shape: rebuild the span tables
+    std::vector<int> rs, rc, cs, cc;
+    std::vector<float> rw, cw;
+    build_resize_spans(H, S, rs, rc, rw, ctx->rs_row_span);
+    build_resize_spans(W, S, cs, cc, cw, ctx->rs_col_span);
+    std::vector<float> host;                                    // [row start | row count | col start | col count] as ints, then weights
+    host.resize((size_t)4 * S + rw.size() + cw.size());
+    memcpy(host.data(), rs.data(), (size_t)S * 4); memcpy(host.data() + S, rc.data(), (size_t)S * 4);
+    memcpy(host.data() + 2 * S, cs.data(), (size_t)S * 4); memcpy(host.data() + 3 * S, cc.data(), (size_t)S * 4);
+    memcpy(host.data() + 4 * S, rw.data(), rw.size() * 4); memcpy(host.data() + 4 * S + rw.size(), cw.data(), cw.size() * 4);
+    HIPCHK(ctx, hipStreamSynchronize(st));                      // a previous call may still read the old tables
+    HIPCHK(ctx, ctx->rs_tab.alloc(host.size() * 4));
+    HIPCHK(ctx, hipMemcpy(ctx->rs_tab.p, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    ctx->rs_H = H; ctx->rs_W = W;
+  }
+  const size_t need_rows = (size_t)B * S * W * 3 * 4, need_img = (size_t)B * S * S * 3 * 4;
+  if (ctx->rs_rows.bytes < need_rows || ctx->rs_img.bytes < need_img) {
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (ctx->rs_rows.bytes < need_rows) HIPCHK(ctx, ctx->rs_rows.alloc(need_rows));
+    if (ctx->rs_img.bytes < need_img) HIPCHK(ctx, ctx->rs_img.alloc(need_img));
+  }
+  const int* ti = ctx->rs_tab.as<int>();
+  const float* tw = ctx->rs_tab.as<float>() + 4 * S;
+  HIPCHK(ctx, launch_resize(frames, images, ctx->rs_rows.as<float>(), ctx->rs_img.as<float>(), ti, ti + S, tw,
+                            ctx->rs_row_span, ti + 2 * S, ti + 3 * S, tw + (size_t)S * ctx->rs_row_span, ctx->rs_col_span, B, H, W,
+                            S, crop != 0, st));
   return HVLA_OK;
 }
 

@@ -87,6 +87,13 @@ hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const E
 hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st);
 
+// ---------------------------------------------------------------- observation preprocessing (resize.hip)
+void build_resize_spans(int in_size, int out_size, std::vector<int>& start, std::vector<int>& count, std::vector<float>& w,
+                        int& maxspan);
+hipError_t launch_resize(const uint8_t* src, uint8_t* dst, float* tmp_rows, float* tmp_img, const int* row_start,
+                         const int* row_count, const float* row_w, int row_span, const int* col_start, const int* col_count,
+                         const float* col_w, int col_span, int B, int H, int W, int S, int crop, hipStream_t st);
+
 // ---------------------------------------------------------------- generated policy
 struct PolicyParams {
   PolicyLayout pl;

@@ -19,7 +19,7 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
-           "hvla_t5_encode"]
+           "hvla_t5_encode", "hvla_preprocess"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy"]
 
 
@@ -91,6 +91,8 @@ def load_library():
     lib.hvla_encode.restype = C.c_int
     lib.hvla_encode_hidden.argtypes = [vp, vp, vp, i32, vp]
     lib.hvla_encode_hidden.restype = C.c_int
+    lib.hvla_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.hvla_preprocess.restype = C.c_int
     lib.hvla_t5_load.argtypes = [vp, C.POINTER(hvla_t5_config), C.POINTER(hvla_tensor_desc), i32]
     lib.hvla_t5_load.restype = C.c_int
     lib.hvla_t5_encode.argtypes = [vp, vp, vp, vp, i32, i32, vp]
@@ -186,6 +188,9 @@ class Context:
         cfg = hvla_t5_config(t.vocab, t.d_model, t.d_kv, t.heads, t.d_ff, t.layers, t.buckets, t.max_distance, t.eps,
                              max_tokens, max_batch)
         self._check(self.lib.hvla_t5_load(self.h, C.byref(cfg), descs, len(params)), "hvla_t5_load")
+
+    def preprocess(self, src_ptr, B, H, W, crop, dst_ptr, stream=0):
+        self._check(self.lib.hvla_preprocess(self.h, src_ptr, B, H, W, int(crop), dst_ptr, C.c_void_p(stream)), "hvla_preprocess")
 
     def t5_encode(self, ids_ptr, mask_ptr, out_ptr, B, T, stream=0):
         self._check(self.lib.hvla_t5_encode(self.h, ids_ptr, mask_ptr, out_ptr, B, T, C.c_void_p(stream)), "hvla_t5_encode")

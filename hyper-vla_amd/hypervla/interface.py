@@ -5,7 +5,7 @@ Given identical post-resize ``uint8[224,224,3]`` observations it reproduces the 
 history / pad-mask bookkeeping (:123-139), un-normalisation (:219-242), temporal ensemble (:250-253,
 == data/utils/action_ensemble.py:15-27 with temperature 0), euler -> axis-angle (:261-267), the
 per-``policy_setup`` gripper rules (:269-299) and the 5-tuple it returns (:304).  The lanczos3 resize
-(:89-121) is upstream of the parity boundary: frames must already be image_size².
+(:89-121) runs on the device (hvla_preprocess); padded_resize is not built.
 """
 from __future__ import annotations
 
@@ -94,10 +94,14 @@ class InferenceWrapper:
         self.sticky_gripper_action, self.previous_gripper_action = 0.0, None
 
     def _resize_image(self, image: np.ndarray) -> np.ndarray:
-        if image.shape[:2] != (self.image_size, self.image_size) or self.crop or self.padded_resize:
-            raise NotImplementedError("on-device lanczos3 resize / crop is the next widening row (SURVEY.md §8f N3); "
-                                      f"pass {self.image_size}x{self.image_size} uint8 frames")
-        return image
+        """hypervla_interface.py:89-121 on the device (lanczos3 antialias resize, optional sqrt(0.9) crop)."""
+        if self.padded_resize:
+            raise NotImplementedError("padded_resize (tf.image.resize_with_pad to 256x320) is not built")
+        if image.shape[:2] == (self.image_size, self.image_size) and not self.crop:
+            return image                       # a same-size lanczos3 resize reproduces the uint8 frame
+        if self.image_size != self.model.geometry.image_size:
+            raise ValueError(f"image_size {self.image_size} != the model's {self.model.geometry.image_size}")
+        return self.model.preprocess_images(np.asarray(image), crop=self.crop)[0].cpu().numpy()
 
     def initial_state_from_image(self, image: np.ndarray):
         """The dict the evaluators assemble before `reset` (data/simpler/evaluate.py:264-274), with the DINOv2

@@ -169,6 +169,22 @@ class HyperVLA:
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(np.asarray(a))).to(device=self.device, dtype=dtype).contiguous()
 
+    # ------------------------------------------------------------------ observation preprocessing
+    def preprocess_images(self, frames, crop: bool = False):
+        """`InferenceWrapper._resize_image` (data/utils/hypervla_interface.py:89-121, no padded_resize) on the device:
+        uint8 camera frames [B, H, W, 3] (or [H, W, 3]) -> uint8 [B, image_size, image_size, 3] CUDA tensor."""
+        torch = _torch()
+        f = self._dev(frames, torch.uint8)
+        if f.dim() == 3:
+            f = f[None].contiguous()
+        if f.dim() != 4 or f.shape[-1] != 3:
+            raise ValueError(f"frames must be [B, H, W, 3] uint8, got {tuple(f.shape)}")
+        B, H, W, _ = f.shape
+        S = self.geometry.image_size
+        out = torch.empty(B, S, S, 3, dtype=torch.uint8, device=self.device)
+        self._ctx.preprocess(f.data_ptr(), B, H, W, crop, out.data_ptr(), self._stream())
+        return out
+
     # ------------------------------------------------------------------ frozen instruction encoder (optional)
     def load_language_encoder(self, t5_params: Dict[str, np.ndarray], t5_geometry=None, max_batch: Optional[int] = None):
         """Put the frozen T5 encoder of `LanguageTokenizer('t5-base')` on the device

@@ -104,11 +104,11 @@ def test_wrapper_chain_matches_golden(golden_dir, setup, ens):
         assert (np.abs(np.stack(acts)[:, -1]) > 0.5).sum() >= 15             # sticky gripper exercised
 
 
-def test_wrapper_rejects_unresized_frames_and_bad_setup():
+def test_wrapper_rejects_padded_resize_and_bad_setup():
     m = _FakeModel(np.zeros((1, 4, 7)))
     with pytest.raises(ValueError):
         InferenceWrapper(m, policy_setup="metaworld")
-    w = InferenceWrapper(m, policy_setup="libero", pred_action_horizon=4, image_size=224)
+    w = InferenceWrapper(m, policy_setup="libero", pred_action_horizon=4, image_size=224, padded_resize=True)
     w.reset("t", {"language_instruction": {}}, {})
     with pytest.raises(NotImplementedError):
         w.step(np.zeros((480, 640, 3), np.uint8))

@@ -170,3 +170,27 @@ def test_t5_restatement_matches_transformers_torch_t5():
             rp = torch.arange(T_)[None, :] - torch.arange(T_)[:, None]
             np.testing.assert_array_equal(blk._relative_position_bucket(rp, True, t.buckets, t.max_distance).numpy(),
                                           onp.t5_relative_buckets(T_, t.buckets, t.max_distance))
+
+
+def test_image_preprocessing_restatement_properties():
+    """tf.image.resize(lanczos3, antialias) + crop_and_resize restatement (no TensorFlow here: parity unpinned): span
+    weights are normalised, a same-size resize is the identity on uint8, constants stay constant through both stages,
+    down-scaling by an integer factor of a smooth ramp keeps the ramp."""
+    rng = np.random.default_rng(3)
+    for n_in, n_out in ((640, 224), (480, 224), (224, 224), (128, 224)):
+        spans = onp.resize_spans(n_in, n_out)
+        assert len(spans) == n_out
+        for s, w in spans:
+            assert 0 <= s and s + len(w) <= n_in and abs(float(w.sum()) - 1.0) < 1e-5
+    sq = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(onp.preprocess_image(sq, 40), sq)
+    const = np.full((48, 64, 3), 77, np.uint8)
+    assert (onp.preprocess_image(const, 28) == 77).all() and (onp.preprocess_image(const, 28, crop=True) == 77).all()
+    ramp = np.broadcast_to((np.arange(96, dtype=np.float32) * 2.0)[None, :, None], (96, 96, 3))
+    small = onp.resize_lanczos3(ramp, 32)
+    want = (np.arange(32) + 0.5) * 3.0 * 2.0 - 1.0                       # value of the ramp at each output pixel's centre
+    np.testing.assert_allclose(small[16, 4:-4, 0], want[4:-4], atol=0.05)
+    # the crop keeps the centre: pixel (S-1)/2 maps to (S-1)/2
+    img = rng.integers(0, 256, (31, 31, 3)).astype(np.float32)
+    c = onp.crop_and_resize_bilinear(img, 31)
+    np.testing.assert_allclose(c[15, 15], img[15, 15], atol=1e-3)
