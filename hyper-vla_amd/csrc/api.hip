@@ -75,6 +75,7 @@ struct hvla_ctx {
   // workspaces (sized for cfg.max_batch)
   DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, tokens, flags;
   Profiler prof;
+
   // observation preprocessing (hvla_preprocess): span tables of the last (H, W) and scratch
   int rs_H = 0, rs_W = 0, rs_row_span = 0, rs_col_span = 0;
   DevBuf rs_tab, rs_rows, rs_img;
@@ -747,6 +748,26 @@ int hvla_debug_gemm(hvla_ctx* ctx, int M, int N, int K, int epi, int variant, in
   const float* bias = epi == 1 ? L.bqkv : (epi == 2 ? L.b1 : L.b2);
   HIPCHK(ctx, debug_gemm(A, W, bias, L.ls1, out, M, N, K, epi, variant, iters, ms, nullptr));
   return HVLA_OK;
+}
+
+// diagnostics (not part of include/hvla.h): time one shape of the fine-tune path's batched GEMM on caller buffers
+int hvla_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, int nb, int accumulate,
+                     int iters, float* ms) {
+  const int lda = ta ? M : K, ldb = tb ? K : N;
+  BG g{A, B, C, nullptr, M, N, K, lda, ldb, N, (long)M * K, 0, (long)N * K, 0, (long)M * N, 0, 0, 1, 1.f, accumulate};
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) bgemm(nullptr, ta != 0, tb != 0, g, nb);
+  (void)hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters; ++i) bgemm(nullptr, ta != 0, tb != 0, g, nb);
+  (void)hipEventRecord(e1, nullptr);
+  (void)hipEventSynchronize(e1);
+  (void)hipEventElapsedTime(ms, e0, e1);
+  *ms /= iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return hipGetLastError() == hipSuccess ? HVLA_OK : HVLA_E_HIP;
 }
 
 int hvla_selftest(hvla_ctx* ctx, void* stream) {

@@ -100,43 +100,80 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
 //   T = true   source is row-contiguous (memory [k][row]): LDS image [k][BR + 32], no transposition while staging;
 //              the fragment's k-in-lane order comes from ds_read_b64_tr_b16 (two per plane and k chunk)
 // Either way a thread moves float4's along the contiguous dimension (scalar fallback for unaligned / edge pieces).
-// Loads are branch-free (clamped address + select) so that the compiler keeps counted s_waitcnt vmcnt: VEC = one
-// float4 per piece (host guarantees 16-byte alignment and that pieces never straddle the K / row edge), else 4 dwords.
+// Loads are branch-free so that the compiler keeps counted s_waitcnt vmcnt: VEC = one float4 per piece (host guarantees
+// 16-byte alignment and that pieces never straddle the K / row edge), else 4 dwords.
+// Out-of-range pieces are read from this block of zeros: selecting the ADDRESS keeps the load free of any instruction that
+// consumes its result (a `v = ok ? v : 0` after the load would make the wave wait for the data right there and undo the
+// prefetch).
+__device__ __attribute__((aligned(16))) float hvla_zero_piece[4] = {0.f, 0.f, 0.f, 0.f};
+
+// The loads are written as inline asm so that the compiler does not track them: it would otherwise place its own
+// (conservative, often vmcnt(0)) waits wherever it schedules the consumers and drain the younger stages with them.  The
+// kernel waits for exactly one stage with a constant s_waitcnt vmcnt and pins the consumers behind it with tie().
+// One stage of one operand in registers: P pieces of 4 consecutive elements, as float4 tuples (VEC) or as 4P scalars.
+// Each register is written by exactly one asm load and first touched again by tie() after the wait -- never copied in
+// between (the hardware does not interlock a VGPR read against a load still in flight).
+template <int P, bool VEC> struct StageRegs;
+template <int P> struct StageRegs<P, true> {
+  f32x4 v[P];
+  __device__ __forceinline__ float get(int j, int c) const { return v[j][c]; }
+};
+template <int P> struct StageRegs<P, false> {
+  float f[4 * P];
+  __device__ __forceinline__ float get(int j, int c) const { return f[4 * j + c]; }
+};
+#define HVLA_T(x) "+v"(x)
+__device__ __forceinline__ void tie(StageRegs<4, true>& r) { asm volatile("" : HVLA_T(r.v[0]), HVLA_T(r.v[1]), HVLA_T(r.v[2]), HVLA_T(r.v[3])::"memory"); }
+__device__ __forceinline__ void tie(StageRegs<2, true>& r) { asm volatile("" : HVLA_T(r.v[0]), HVLA_T(r.v[1])::"memory"); }
+__device__ __forceinline__ void tie(StageRegs<2, false>& r) {
+  asm volatile("" : HVLA_T(r.f[0]), HVLA_T(r.f[1]), HVLA_T(r.f[2]), HVLA_T(r.f[3]), HVLA_T(r.f[4]), HVLA_T(r.f[5]), HVLA_T(r.f[6]), HVLA_T(r.f[7])::"memory");
+}
+__device__ __forceinline__ void tie(StageRegs<4, false>& r) {
+  asm volatile("" : HVLA_T(r.f[0]), HVLA_T(r.f[1]), HVLA_T(r.f[2]), HVLA_T(r.f[3]), HVLA_T(r.f[4]), HVLA_T(r.f[5]), HVLA_T(r.f[6]), HVLA_T(r.f[7]),
+               HVLA_T(r.f[8]), HVLA_T(r.f[9]), HVLA_T(r.f[10]), HVLA_T(r.f[11]), HVLA_T(r.f[12]), HVLA_T(r.f[13]), HVLA_T(r.f[14]), HVLA_T(r.f[15])::"memory");
+}
+#undef HVLA_T
+
 template <bool T, int BR, bool VEC>
 __device__ __forceinline__ void stage_load(const float* __restrict__ P, int ld, int r0, int R, int k0, int kend,
-                                           float4 (&out)[BR * 8 / 256]) {
+                                           StageRegs<BR * 8 / 256, VEC>& out) {
 #pragma unroll
   for (int j = 0; j < BR * 8 / 256; ++j) {
     const int idx = threadIdx.x + j * 256;
     const int r = r0 + (T ? (idx % (BR / 4)) * 4 : idx >> 3), k = k0 + (T ? idx / (BR / 4) : (idx & 7) * 4);
     const bool ok = r < R && k < kend;
-    const long base = T ? (long)k * ld + r : (long)r * ld + k;
-    const long step = T ? 1 : 1;                          // the 4 elements of a piece are adjacent in memory either way
-    float4 v;
-    if (VEC) {
-      v = *reinterpret_cast<const float4*>(P + (ok ? base : 0));
-      if (!ok) v = float4{0.f, 0.f, 0.f, 0.f};
+    const float* p = P + (T ? (long)k * ld + r : (long)r * ld + k);     // the 4 elements of a piece are adjacent in memory
+    if constexpr (VEC) {
+      const float* q = ok ? p : hvla_zero_piece;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(out.v[j]) : "v"(q) : "memory");
     } else {
       const int lim = T ? R - r : kend - k;               // valid elements in this piece (<= 0: none)
-      const bool o0 = ok, o1 = ok && lim > 1, o2 = ok && lim > 2, o3 = ok && lim > 3;
-      const float x0 = P[o0 ? base : 0], x1 = P[o1 ? base + step : 0], x2 = P[o2 ? base + 2 * step : 0], x3 = P[o3 ? base + 3 * step : 0];
-      v = float4{o0 ? x0 : 0.f, o1 ? x1 : 0.f, o2 ? x2 : 0.f, o3 ? x3 : 0.f};
+      const float* z = hvla_zero_piece;
+      const float *q0 = ok ? p : z, *q1 = ok && lim > 1 ? p + 1 : z, *q2 = ok && lim > 2 ? p + 2 : z, *q3 = ok && lim > 3 ? p + 3 : z;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(out.f[4 * j + 0]) : "v"(q0) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=v"(out.f[4 * j + 1]) : "v"(q1) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=v"(out.f[4 * j + 2]) : "v"(q2) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=v"(out.f[4 * j + 3]) : "v"(q3) : "memory");
     }
-    out[j] = v;
   }
 }
-template <bool T, int BR>
-__device__ __forceinline__ void stage_store(__bf16* __restrict__ hi, __bf16* __restrict__ lo, const float4 (&in)[BR * 8 / 256]) {
+template <bool T, int BR, bool VEC>
+__device__ __forceinline__ void stage_store(__bf16* __restrict__ hi, __bf16* __restrict__ lo, const StageRegs<BR * 8 / 256, VEC>& in) {
 #pragma unroll
   for (int j = 0; j < BR * 8 / 256; ++j) {
     const int idx = threadIdx.x + j * 256;
     const int o = T ? (idx / (BR / 4)) * (BR + 32) + (idx % (BR / 4)) * 4 : (idx >> 3) * 40 + (idx & 7) * 4;
     bf16x4 h, l;
     __bf16 a, b;
-    split1(in[j].x, a, b); h[0] = a; l[0] = b;
-    split1(in[j].y, a, b); h[1] = a; l[1] = b;
-    split1(in[j].z, a, b); h[2] = a; l[2] = b;
-    split1(in[j].w, a, b); h[3] = a; l[3] = b;
+#ifdef HVLA_ABL_NOSPLIT      // timing ablation only (wrong numbers): what a pre-split operand would cost to stage
+    *reinterpret_cast<float2*>(hi + o) = float2{in.get(j, 0), in.get(j, 1)};
+    *reinterpret_cast<float2*>(lo + o) = float2{in.get(j, 2), in.get(j, 3)};
+    continue;
+#endif
+    split1(in.get(j, 0), a, b); h[0] = a; l[0] = b;
+    split1(in.get(j, 1), a, b); h[1] = a; l[1] = b;
+    split1(in.get(j, 2), a, b); h[2] = a; l[2] = b;
+    split1(in.get(j, 3), a, b); h[3] = a; l[3] = b;
     *reinterpret_cast<bf16x4*>(hi + o) = h;
     *reinterpret_cast<bf16x4*>(lo + o) = l;
   }
@@ -174,7 +211,11 @@ __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, IN = WN / 32;
   constexpr bool SA = TA, SB = !TB;                       // staging flavour: row-contiguous source?
   constexpr int NA = SA ? 32 * (BM + 32) : BM * 40, NB = SB ? 32 * (BN + 32) : BN * 40;
-  constexpr int NST = 3;                                  // k steps of global loads in flight (register stages)
+  // k steps of global loads in flight (register stages): three float4 stages, or two when every piece is 4 dwords
+  // (the 6-bit vmcnt could not count three of those)
+  constexpr int NST = VEC ? 3 : 2;
+  constexpr int PA = BM * 8 / 256, PB = BN * 8 / 256;     // float4 pieces per thread and stage
+  constexpr int LPS = (PA + PB) * (VEC ? 1 : 4);          // load instructions per stage
   __shared__ __attribute__((aligned(16))) __bf16 Ah[NA], Al[NA], Bh[NB], Bl[NB];
   const int zb = blockIdx.z / g.ksplit, kc = blockIdx.z % g.ksplit;
   const int b0 = zb / g.nb1, b1 = zb % g.nb1;
@@ -193,27 +234,32 @@ __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
     for (int b = 0; b < IN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float4 ra[NST][BM * 8 / 256], rb[NST][BN * 8 / 256];
+  StageRegs<PA, VEC> ra[NST];
+  StageRegs<PB, VEC> rb[NST];
 #pragma unroll
-  for (int s2 = 0; s2 < NST; ++s2) {                      // out-of-range steps load zeros (k >= kend)
+  for (int s2 = 0; s2 < NST; ++s2) {                      // steps past kend read the block of zeros
     stage_load<SA, BM, VEC>(A, g.lda, m0, g.M, kbeg + 32 * s2, kend, ra[s2]);
     stage_load<SB, BN, VEC>(B, g.ldb, n0, g.N, kbeg + 32 * s2, kend, rb[s2]);
   }
-  // Straight-line body (no branch around the refill loads): the compiler can then wait for exactly the oldest
-  // register stage with a counted s_waitcnt vmcnt while the two younger stages stay in flight.
+  // Whole groups of NST steps (a step past kend multiplies staged zeros), every step issues its refill: the number of
+  // loads in flight is the same at every wait, so the wait for the oldest stage is the constant vmcnt((NST - 1) * LPS).
   for (int k0 = kbeg; k0 < kend; k0 += 32 * NST) {
 #pragma unroll
     for (int s2 = 0; s2 < NST; ++s2) {
       const int kcur = k0 + 32 * s2;
-      if (kcur >= kend) break;                            // uniform over the workgroup; leaves the loop for good
-      // raw barriers: a __syncthreads() would also drain the two younger register stages' global loads (vmcnt(0))
+      // raw barriers: a __syncthreads() would also drain the younger register stages' global loads (vmcnt(0))
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the previous step's fragment reads are done
-      stage_store<SA, BM>(Ah, Al, ra[s2]);
-      stage_store<SB, BN>(Bh, Bl, rb[s2]);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * LPS) : "memory");     // the oldest stage has landed
+      tie(ra[s2]);
+      tie(rb[s2]);
+      stage_store<SA, BM, VEC>(Ah, Al, ra[s2]);
+      stage_store<SB, BN, VEC>(Bh, Bl, rb[s2]);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the LDS image is complete
-      // refill this register stage NST steps ahead (lanes past kend just get zeros)
+      // refill this register stage NST steps ahead
+#ifndef HVLA_ABL_NOLOAD      // timing ablation only
       stage_load<SA, BM, VEC>(A, g.lda, m0, g.M, kcur + 32 * NST, kend, ra[s2]);
       stage_load<SB, BN, VEC>(B, g.ldb, n0, g.N, kcur + 32 * NST, kend, rb[s2]);
+#endif
 #pragma unroll
       for (int kk = 0; kk < 32; kk += 16) {
         Split8 fa[IM], fb[IN];
@@ -224,10 +270,17 @@ __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
 #pragma unroll
         for (int a = 0; a < IM; ++a)
 #pragma unroll
-          for (int b = 0; b < IN; ++b) acc[a][b] = mma32_x3(fa[a], fb[b], acc[a][b]);
+          for (int b = 0; b < IN; ++b) {
+#ifdef HVLA_ABL_NOMFMA       // timing ablation only: keep the fragment reads alive without the matrix cores
+            acc[a][b][0] += (float)fa[a].hi[0] + (float)fb[b].lo[0];
+#else
+            acc[a][b] = mma32_x3(fa[a], fb[b], acc[a][b]);
+#endif
+          }
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the refills past kend (zeros) are still in flight
   const float* bias = g.bias && kc == 0 ? g.bias + b0 * g.sBias0 : nullptr;
 #pragma unroll
   for (int b = 0; b < IN; ++b) {
