@@ -317,9 +317,7 @@ static bool train_gemm_exact() {
 
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
   const bool exact = train_gemm_exact();
-  static const long min128 = [] { const char* e = getenv("HVLA_MIN128"); return e ? atol(e) : 0L; }();
-  int T = !exact && g.M >= 96 && g.N >= 96 ? 128 : 64;
-  if (T == 128 && (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * nb0 * g.nb1 * (g.accumulate ? 8 : 1) < min128) T = 64;
+  const int T = !exact && g.M >= 96 && g.N >= 96 ? 128 : 64;
   // deep-K products onto few output tiles (shared-weight gradients: K = all rows of the batch) would leave most CUs
   // idle: cut K so that the grid has >= ~256 workgroups (one per CU; more only adds atomic traffic); legal whenever the result is accumulated (C zeroed before)
   const long tiles = (long)((g.N + T - 1) / T) * ((g.M + T - 1) / T) * nb0 * g.nb1;
