@@ -13,7 +13,7 @@ M = B * 257 - int(os.environ.get('HVLA_DBG_MSHRINK', '0'))
 shapes = {"qkv": (M, 2304, 768, 1), "out": (M, 768, 768, 3), "fc1": (M, 3072, 768, 2), "fc2": (M, 768, 3072, 3)}
 names = {0: "128x128 regstage", 1: "256x256 lds-dma", 2: "256 no-DMA-in-loop", 3: "256 no-MFMA", 4: "ring5 8 waves", 5: "256 ring4", 6: "ring4 no-DMA", 7: "ring4 no-MFMA", 8: "ring4 DMA-only"}
 for nm, (M_, N, K, epi) in shapes.items():
-    for variant in (5, 4):
+    for variant in (tuple(int(v) for v in os.environ["HVLA_VARIANTS"].split(",")) if "HVLA_VARIANTS" in os.environ else (5, 4)):
         if variant >= 6 and nm != "qkv" and nm != "fc2":
             continue
         ms = C.c_float()
