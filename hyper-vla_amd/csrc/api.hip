@@ -754,7 +754,7 @@ int hvla_debug_gemm(hvla_ctx* ctx, int M, int N, int K, int epi, int variant, in
 int hvla_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, int nb, int accumulate,
                      int iters, float* ms) {
   const int lda = ta ? M : K, ldb = tb ? K : N;
-  BG g{A, B, C, nullptr, M, N, K, lda, ldb, N, (long)M * K, 0, (long)N * K, 0, (long)M * N, 0, 0, 1, 1.f, accumulate};
+  BG g{A, B, C, nullptr, M, N, K, lda, ldb, N, (long)M * K, 0, (long)N * K, 0, (long)M * N, 0, 0, 1, 1.f, accumulate, 1, accumulate != 0};
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);

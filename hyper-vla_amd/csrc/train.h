@@ -20,6 +20,8 @@ struct BG {
   float alpha;
   int accumulate;             // 0 store, 1 C += (one writer per element), 2 atomic C += (batches share C)
   int ksplit = 1;             // > 1: K is cut into ksplit chunks over blockIdx.z, reduced with atomics (accumulate != 0)
+  int allow_split = 0;        // 1: the launcher may choose ksplit > 1 itself (deep-K gradient products; result then
+                              //    depends on the order of the atomic adds in its last bits)
 };
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0);
 

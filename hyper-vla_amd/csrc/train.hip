@@ -322,7 +322,7 @@ void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
   // idle: cut K so that the grid has >= ~256 workgroups (one per CU; more only adds atomic traffic); legal whenever the result is accumulated (C zeroed before)
   const long tiles = (long)((g.N + T - 1) / T) * ((g.M + T - 1) / T) * nb0 * g.nb1;
   static const long want = [] { const char* e = getenv("HVLA_KSPLIT_TILES"); return e ? atol(e) : 256L; }();
-  if (g.accumulate != 0 && g.ksplit == 1 && tiles < want && g.K >= 256) {
+  if (g.allow_split && g.accumulate != 0 && g.ksplit == 1 && tiles < want && g.K >= 256) {
     long ks = (want + tiles - 1) / tiles, kmax = g.K / 128;
     g.ksplit = (int)(ks < kmax ? ks : kmax);
     if (g.ksplit < 1) g.ksplit = 1;
@@ -876,7 +876,7 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
   const int hd = D / H, rows = nb * S;
   const bool shared = gs == 0;
   auto wgrad = [&](const float* X, int K, const float* dY, int N, float* dW) {   // dW[K][N] (+)= X^T dY
-    if (shared) bgemm(st, true, false, BG{X, dY, dW, nullptr, K, N, rows, K, N, N, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);
+    if (shared) bgemm(st, true, false, BG{X, dY, dW, nullptr, K, N, rows, K, N, N, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1, 1, 1}, 1);
     else bgemm(st, true, false, BG{X, dY, dW, nullptr, K, N, S, K, N, N, (long)S * K, 0, (long)S * N, 0, gs, 0, 0, 1, 1.f, 1}, nb);
   };
   auto bgrad = [&](const float* dY, int N, float* dB) {
@@ -1081,7 +1081,7 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   KL(colsum_kernel, dim3((unsigned)((G + 63) / 64), 1, (B + 63) / 64), dim3(64), tb.dtheta, Gm + L.bcat, 0, B, B, (int)G, 1);                  // db_cat
   (void)hipMemsetAsync(dctx, 0, (size_t)B * C * 4, st);
   // dctx = dtheta W_cat^T: [B, G] x [G, C], a K = 201 500 product onto a B x C output -> split-K over the whole chip
-  bgemm(st, false, true, BG{tb.dtheta, Pm + L.wcat, dctx, nullptr, B, C, (int)G, (int)G, (int)G, C, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);
+  bgemm(st, false, true, BG{tb.dtheta, Pm + L.wcat, dctx, nullptr, B, C, (int)G, (int)G, (int)G, C, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1, 1, 1}, 1);
   // =============================== context encoder backward ===============================
   (void)hipMemsetAsync(cdx, 0, (size_t)B * Sc * C * 4, st);
   KL(ctx_final_bwd_kernel, dim3((B + 3) / 4), dim3(256), cx_fin + (long)(Sc - 1) * C, (long)Sc * C, dctx, cmean, crstd, Pm + L.norm_s, cdx + (long)(Sc - 1) * C, Gm + L.norm_s, Gm + L.norm_b, B, C, g.scale_context ? 1.f / sqrtf((float)C) : 1.f);

@@ -315,7 +315,9 @@ def test_t5_instruction_encoder(full):
     m.load_language_encoder(tp, T5_MID)
     tok = syn.synthetic_token_ids(B, T5_MID, g.lang_tokens)
     tok["attention_mask"][0] = 1                                       # one sequence without padding
-    got = m.encode_instructions(tok)["token_embedding"].cpu().numpy().astype(np.float64)
+    emb = m.encode_instructions(tok)["token_embedding"]
+    assert torch.equal(emb, m.encode_instructions(tok)["token_embedding"])          # no order-dependent reduction
+    got = emb.cpu().numpy().astype(np.float64)
     ref = onp.t5_encoder(tp, T5_MID, tok["input_ids"], tok["attention_mask"])
     keep = tok["attention_mask"].astype(bool)
     assert got.shape == ref.shape == (B, g.lang_tokens, g.lang_dim)
