@@ -410,3 +410,60 @@ def test_policy_kernel_is_run_to_run_deterministic(full):
         torch.cuda.synchronize()
         assert int(((acts != acts[0]).reshape(runs, -1).any(1)).sum()) == 0
         assert int(((lgs != lgs[0]).reshape(runs, -1).any(1)).sum()) == 0
+
+
+@pytest.mark.timeout(900)
+def test_config3_size_graph_replay_and_invariance():
+    """BASELINE configs[2] size (2048 episodes, hipGraph-captured step with the device-side ensemble): the replayed graph
+    gives the bytes of the eager step, and episodes sampled from the big batch equal the same episodes in a batch of 64."""
+    _need_gpu()
+    from hypervla import synthetic as syn
+    from hypervla.config import FULL
+    from hypervla.model import HyperVLA
+    g, B = FULL, 2048
+    m = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g)
+    im = torch.as_tensor(syn.synthetic_images(B, g)[:, 0]).to(m.device).contiguous()
+    w, tasks, _ = m.create_tasks(instruction_dict=ins, initial_state=st)
+    ctx = m._ctx
+    stats = syn.synthetic_dataset_statistics(g)["bridge_dataset"]["action"]
+    mean, std = torch.as_tensor(stats["mean"]).to(m.device), torch.as_tensor(stats["std"]).to(m.device)
+    mask = torch.as_tensor(stats["mask"].astype(np.uint8)).to(m.device)
+    act, lg = torch.empty(B, g.horizon, g.action_dim, device=m.device), torch.empty(B, g.horizon, device=m.device)
+    out = torch.empty(B, g.action_dim, device=m.device)
+
+    def step(stream):
+        ctx.step(w._h, im.data_ptr(), act.data_ptr(), lg.data_ptr(), B, stream)
+        ctx.ensemble(w._h, act.data_ptr(), mean.data_ptr(), std.data_ptr(), mask.data_ptr(), out.data_ptr(), stream)
+
+    ctx.ensemble_reset(w._h, m._stream())
+    eager = []
+    for _ in range(3):
+        step(m._stream())
+        eager.append((act.clone(), out.clone()))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(m.device)
+    with torch.cuda.stream(side):
+        ctx.ensemble_reset(w._h, m._stream())
+        step(m._stream())                                   # warm the side stream; ring now holds 1 prediction
+        side.synchronize()
+        ctx.ensemble_reset(w._h, m._stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step(m._stream())
+    torch.cuda.synchronize()
+    ctx.ensemble_reset(w._h, m._stream())
+    for i in range(3):                                      # same 3 steps, replayed
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(act, eager[i][0]) and torch.equal(out, eager[i][1]), i
+    # batch invariance at this size
+    full_a = eager[0][0].cpu().numpy()
+    li = ins["language_instruction"]
+    for lo in (0, 1000, 1984):
+        idx = np.arange(lo, lo + 64)
+        sub_ins = {"language_instruction": {k: np.asarray(v)[idx] for k, v in li.items()}}
+        sub_st = {"patch_embeddings": st["patch_embeddings"][idx], "pad_mask_dict": {"image_primary": np.ones((64, 1))}}
+        ws, ts, _ = m.create_tasks(instruction_dict=sub_ins, initial_state=sub_st)
+        a, _ = m.sample_actions(im[idx].cpu().numpy(), sub_ins, ts, np.ones((64, 1)), base_params=ws)
+        np.testing.assert_array_equal(np.asarray(a), full_a[lo:lo + 64])

@@ -226,3 +226,34 @@ def test_encoder_training_reduces_loss():
     losses = [float(ft.step(ins, st, im, batch, lr=1e-3, base_lr=1e-4)) for _ in range(8)]
     assert losses[-1] < losses[0], losses
     assert float((ft.params[ft.n_hyper:] - before).abs().max()) > 0      # the encoder really moved
+
+
+@pytest.mark.timeout(900)
+def test_full_geometry_gradient_is_the_mean_of_per_sample_gradients():
+    """Size-independent property at the README geometry with the encoder trained (no oracle needed): the loss is a mean
+    over independent episodes (scripts/train.py:453-457), so grads(batch of 6) == mean_b grads(episode b alone)."""
+    from hypervla import synthetic as syn
+    from hypervla.config import FULL
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner
+    g, B = FULL, 6
+    model = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    batch = syn.synthetic_action_batch(B, g)
+    batch["timestep_pad_mask"][:] = True                       # keep every sample in the mean
+    ft = FineTuner(model, B, train_encoder=True)
+    loss = ft.forward_backward(ins, st, im, batch).clone()
+    big = ft.grads.clone()
+    one = FineTuner(model, 1, train_encoder=True)
+    acc = torch.zeros_like(big)
+    li = ins["language_instruction"]
+    for b in range(B):
+        sl = slice(b, b + 1)
+        l1 = one.forward_backward({"language_instruction": {k: np.asarray(v)[sl] for k, v in li.items()}},
+                                  {"patch_embeddings": st["patch_embeddings"][sl]}, im[sl],
+                                  {k: v[sl] for k, v in batch.items()})
+        assert abs(float(l1[0]) - float(loss[b])) <= 2e-5 * max(1.0, abs(float(loss[b])))
+        acc += one.grads
+    acc /= B
+    scale = float(big.abs().max())
+    assert float((acc - big).abs().max()) <= 2e-4 * scale, float((acc - big).abs().max()) / scale
