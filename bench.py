@@ -128,6 +128,9 @@ def main():
                     help="DINOv2-base (README / reference parity, default) or DINOv2-small (E=384, BASELINE configs[1] wording)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (BASELINE config 3)")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: hvla_step runs the two halves of the batch on two streams (more actions/s; per-kernel "
+                         "durations then include time shared with the other half, so the roofline line is not comparable)")
     ap.add_argument("--ensemble", action="store_true",
                     help="include the device-side un-normalise + temporal ensemble in every step (always on with --graph)")
     ap.add_argument("--finetune", action="store_true",
@@ -152,7 +155,7 @@ def main():
     from hypervla.dp import max_over_ranks, whole_job_rate
     from hypervla.model import HyperVLA
     g, B = (SMALL_E if a.encoder == "small" else FULL), a.batch
-    model = HyperVLA.from_synthetic(g, device=local, max_batch=B, enc_dtype=a.enc_dtype)
+    model = HyperVLA.from_synthetic(g, device=local, max_batch=B, enc_dtype=a.enc_dtype, streams=a.streams)
     dev = model.device
     if a.finetune:
         return finetune_bench(a, model, rank, world, use_dist)
@@ -260,13 +263,14 @@ def main():
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_pmc_{nm}_size_by_kernel.csv"))):
                 if "gemm256r_kernel<hvla::OpF16, 2" in row["kernel"]:
                     vals[nm] = float(row["mean"]) * 1024.0
-        if B == 256 and a.enc_dtype == "f16" and a.encoder == "base" and len(vals) == 2:
+        if B == 256 and a.enc_dtype == "f16" and a.encoder == "base" and a.streams == 1 and len(vals) == 2:
             traffic = int(2 * vals["fetch"] + vals["write"])
     except Exception:
         traffic = None
     fl = algorithmic_flops(g)
     dom_ms = dom[0] / max(dom[1], 1)
-    achieved = fl["fc1"] * B / (dom_ms * 1e-3) / 1e12
+    parts = 2 if (a.streams == 2 and B >= 64) else 1       # episodes per fc1 launch = B / parts
+    achieved = fl["fc1"] * (B / parts) / (dom_ms * 1e-3) / 1e12
     ms_per_step = elapsed / a.steps * 1e3
     out = {
         "metric": "actions_per_sec", "value": round(whole_job_rate(B, world, a.steps, elapsed), 2), "unit": "actions/s",
@@ -280,6 +284,7 @@ def main():
                    "parallelism": f"episode-dp{world} (no collectives)",
                    "encoder_operands": a.enc_dtype, "policy_operands": "split-bf16 (bf16x3)",
                    "launch": "hipGraph replay" if a.graph else "eager (about 95 launches per step)",
+                   "streams": a.streams,
                    "ensemble": "device-side un-normalise + temporal ensemble (history = horizon) inside the step"
                                if ens is not None else "not in the step"},
         "latency_samples": len(lat),
@@ -289,7 +294,7 @@ def main():
                      "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_unit": "bytes/launch (HBM-side, PMC: 2*FETCH_SIZE+WRITE_SIZE; algorithmic 510 MB)",
                      "launch_ms": round(dom_ms, 4), "launches_timed": dom[1],
-                     "flops_per_launch": fl["fc1"] * B},
+                     "flops_per_launch": fl["fc1"] * (B // parts)},
         "step_tflops": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12, 2),
         "step_frac_of_peak": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
         "kernel_ms_per_step": breakdown,

@@ -75,7 +75,14 @@ struct hvla_ctx {
   // workspaces (sized for cfg.max_batch)
   DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, tokens, flags;
   Profiler prof;
-
+  // cfg.streams == 2: helper stream and fork / join events of hvla_step
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  ~hvla_ctx() {
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
+  }
   // observation preprocessing (hvla_preprocess): span tables of the last (H, W) and scratch
   int rs_H = 0, rs_W = 0, rs_row_span = 0, rs_col_span = 0;
   DevBuf rs_tab, rs_rows, rs_img;
@@ -152,6 +159,14 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   A(ctx->ws_x, Bm * S * E * 4); A(ctx->ws_h, Bm * S * E * 2); A(ctx->ws_qkv, Bm * S * 3 * E * 2);
   A(ctx->ws_g, gbytes); A(ctx->tokens, Bm * P * E * 4); A(ctx->flags, 64 * sizeof(int));
   if (e != hipSuccess) return HVLA_E_ARENA_FULL;
+  if (c->streams == 2) {
+    if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+      return HVLA_E_HIP;
+  } else if (c->streams != 0 && c->streams != 1) {
+    return HVLA_E_SHAPE;
+  }
   *out = ctx.release();
   return HVLA_OK;
 }
@@ -458,15 +473,24 @@ static int check_step(hvla_ctx* ctx, int32_t B) {
   return HVLA_OK;
 }
 
+// episodes [b0, b0 + nb) of the batch: every per-episode buffer is offset, the workspace slices are disjoint
+static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0, int nb, bool keep_cls, hipStream_t st) {
+  const Geom& g = ctx->g;
+  const size_t S = g.S(), E = g.E, F = g.enc_mlp, rows = (size_t)b0 * S;
+  EncWorkspace ws{ctx->ws_x.as<float>() + rows * E, static_cast<char*>(ctx->ws_h.p) + rows * E * 2,
+                  static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + rows * F * 2};
+  const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
+  HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
+                             &ctx->prof, keep_cls));
+  return HVLA_OK;
+}
+
 int hvla_encode(hvla_ctx* ctx, const uint8_t* images, float* tokens, int32_t B, void* stream) {
   if (!ctx) return HVLA_E_STATE;
   if (int r = check_step(ctx, B)) return r;
   if (!images || !tokens) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p};
-  HIPCHK(ctx, launch_encoder(ctx->g, ctx->cfg.enc_dtype, ctx->encw, ws, images, tokens, B,
-                             reinterpret_cast<hipStream_t>(stream), &ctx->prof));
-  return HVLA_OK;
+  return encode_range(ctx, images, tokens, 0, B, false, reinterpret_cast<hipStream_t>(stream));
 }
 
 int hvla_encode_hidden(hvla_ctx* ctx, const uint8_t* images, float* hidden, int32_t B, void* stream) {
@@ -474,9 +498,20 @@ int hvla_encode_hidden(hvla_ctx* ctx, const uint8_t* images, float* hidden, int3
   if (int r = check_step(ctx, B)) return r;
   if (!images || !hidden) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p};
-  HIPCHK(ctx, launch_encoder(ctx->g, ctx->cfg.enc_dtype, ctx->encw, ws, images, hidden, B,
-                             reinterpret_cast<hipStream_t>(stream), &ctx->prof, true));
+  return encode_range(ctx, images, hidden, 0, B, true, reinterpret_cast<hipStream_t>(stream));
+}
+
+static int policy_range(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float* actions, float* logits, int b0,
+                        int nb, hipStream_t st) {
+  const Geom& g = ctx->g;
+  const PolicyLayout& pl = ctx->lay.pl;
+  PolicyParams p{pl, w->wh.as<__bf16>() + (size_t)b0 * pl.Gm, w->wl.as<__bf16>() + (size_t)b0 * pl.Gm,
+                 w->vf.as<float>() + (size_t)b0 * pl.Gv, tokens + (size_t)b0 * g.P() * g.E,
+                 actions + (size_t)b0 * g.horizon * g.action_dim, logits ? logits + (size_t)b0 * g.horizon : nullptr,
+                 nb, g.E, g.P(), g.L, g.M, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
+  ctx->prof.begin(HVLA_PROF_POLICY, st);
+  HIPCHK(ctx, launch_policy(p, st));
+  ctx->prof.end(HVLA_PROF_POLICY, st);
   return HVLA_OK;
 }
 
@@ -487,21 +522,35 @@ int hvla_policy(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float
   if (B != w->B) FAIL(ctx, HVLA_E_SHAPE, "batch %d != arena batch %d", B, w->B);
   if (!tokens || !actions) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  const Geom& g = ctx->g;
-  PolicyParams p{ctx->lay.pl, w->wh.as<__bf16>(), w->wl.as<__bf16>(), w->vf.as<float>(), tokens, actions, logits,
-                 B, g.E, g.P(), g.L, g.M, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
-  ctx->prof.begin(HVLA_PROF_POLICY, reinterpret_cast<hipStream_t>(stream));
-  HIPCHK(ctx, launch_policy(p, reinterpret_cast<hipStream_t>(stream)));
-  ctx->prof.end(HVLA_PROF_POLICY, reinterpret_cast<hipStream_t>(stream));
-  return HVLA_OK;
+  return policy_range(ctx, w, tokens, actions, logits, 0, B, reinterpret_cast<hipStream_t>(stream));
 }
 
 int hvla_step(hvla_ctx* ctx, const hvla_weights* w, const uint8_t* images, float* actions, float* logits, int32_t B,
               void* stream) {
   if (!ctx || !w) return HVLA_E_STATE;
-  int r = hvla_encode(ctx, images, ctx->tokens.as<float>(), B, stream);
-  if (r) return r;
-  return hvla_policy(ctx, w, ctx->tokens.as<float>(), actions, logits, B, stream);
+  if (int r = check_step(ctx, B)) return r;
+  if (B != w->B) FAIL(ctx, HVLA_E_SHAPE, "batch %d != arena batch %d", B, w->B);
+  if (!images || !actions) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* tokens = ctx->tokens.as<float>();
+  if (!ctx->side || B < 64) {
+    if (int r = encode_range(ctx, images, tokens, 0, B, false, st)) return r;
+    return policy_range(ctx, w, tokens, actions, logits, 0, B, st);
+  }
+  // two halves on two streams: while one half is in an HBM-bound kernel (LayerNorm, a residual epilogue, attention
+  // staging) or in the ragged end of a grid, the other half's GEMM has the matrix cores.  Episodes are independent and
+  // every kernel is batch-invariant, so the bytes are those of the single-stream step.
+  const int b0 = B / 2;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  if (int r = encode_range(ctx, images, tokens, 0, b0, false, st)) return r;
+  if (int r = encode_range(ctx, images, tokens, b0, B - b0, false, ctx->side)) return r;
+  if (int r = policy_range(ctx, w, tokens, actions, logits, 0, b0, st)) return r;
+  if (int r = policy_range(ctx, w, tokens, actions, logits, b0, B - b0, ctx->side)) return r;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+  HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+  return HVLA_OK;
 }
 
 int hvla_ensemble_reset(hvla_ctx* ctx, hvla_weights* w, void* stream) {

@@ -55,6 +55,8 @@ typedef struct hvla_config {
   int32_t scale_context;                     /* hypernetwork.py:191-192                         */
   int32_t max_batch;                         /* workspace is sized for this many episodes       */
   int32_t enc_dtype;                         /* HVLA_ENC_F16 | HVLA_ENC_BF16                    */
+  int32_t streams;                           /* 1 (default, 0 = 1) or 2: hvla_step runs the two halves of a batch of
+                                                >= 64 episodes on two streams, forked from / joined to the caller's  */
 } hvla_config;
 
 /* One named float32 tensor of the hypernetwork checkpoint, HOST memory, reference naming

@@ -467,3 +467,36 @@ def test_config3_size_graph_replay_and_invariance():
         ws, ts, _ = m.create_tasks(instruction_dict=sub_ins, initial_state=sub_st)
         a, _ = m.sample_actions(im[idx].cpu().numpy(), sub_ins, ts, np.ones((64, 1)), base_params=ws)
         np.testing.assert_array_equal(np.asarray(a), full_a[lo:lo + 64])
+
+
+def test_two_stream_step_gives_the_same_bytes():
+    """hvla_config.streams = 2: the two halves of the batch on two streams (also under hipGraph capture) return exactly the
+    single-stream actions."""
+    _need_gpu()
+    from hypervla import synthetic as syn
+    from hypervla.config import FULL
+    from hypervla.model import HyperVLA
+    g, B = FULL, 96
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    outs = []
+    for streams in (1, 2):
+        m = HyperVLA.from_synthetic(g, max_batch=B, streams=streams)
+        w, tasks, _ = m.create_tasks(instruction_dict=ins, initial_state=st)
+        a, inter = m.sample_actions(im, ins, tasks, np.ones((B, 1)), base_params=w)
+        outs.append((np.asarray(a), np.asarray(inter["gripper_logits"])))
+        if streams == 2:                                     # and replayed from a graph
+            img = torch.as_tensor(im[:, 0]).to(m.device).contiguous()
+            act, lg = torch.empty(B, g.horizon, g.action_dim, device=m.device), torch.empty(B, g.horizon, device=m.device)
+            side = torch.cuda.Stream(m.device)
+            with torch.cuda.stream(side):
+                m._ctx.step(w._h, img.data_ptr(), act.data_ptr(), lg.data_ptr(), B, m._stream())
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    m._ctx.step(w._h, img.data_ptr(), act.data_ptr(), lg.data_ptr(), B, m._stream())
+            act.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(act.cpu().numpy(), outs[0][0])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
