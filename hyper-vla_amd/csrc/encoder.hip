@@ -375,6 +375,170 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves, FOUR PHASES per K-tile with the two wave rows running half a phase apart (guide §5 "256^2
+// 8-phase template": counted vmcnt, raw s_barrier, s_setprio around the MFMA clusters, staggered wave groups).
+//   * a phase = { ds_read fragments | issue one 16 KB half-tile of LDS-DMA } barrier { 16 MFMAs = one quadrant of the
+//     wave's 128x64 tile over K = 64 } barrier.  Waves 4-7 execute one extra barrier up front, so while waves 0-3 are in
+//     their MFMA cluster waves 4-7 (the other wave on each SIMD) read LDS / issue DMA, and vice versa: the matrix pipe and
+//     the LDS / memory pipes are both busy all the time instead of all eight waves wanting the same pipe at once.
+//   * all fragments of a K-tile are read in its first two phases (A rows 0-63 + W rows 0-31, then A rows 64-127 + W rows
+//     32-63 of the wave's tile), so its LDS buffer is free from phase 3 on; tile t+2's A halves are staged there in phases
+//     3 and 4 of tile t, its W halves in phases 1 and 2 of tile t+1.  The wait in phase 4 is the constant vmcnt(4): tile
+//     t+1 has landed, the two A halves of tile t+2 stay in flight across the barriers.
+//   * the last two K-tiles are peeled (nothing is staged past the end, the wait constants stay immediates).
+// LDS image and swizzle are those of gemm256_kernel (128-byte rows, chunk ^= row & 7 on the source and on the read).
+template <typename Op, int EPI, bool PEEL = true>
+__global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
+  using T = typename Op::elem;
+  using X8 = typename Op::x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 buffers x (A 32 KB | W 32 KB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbm = (g.M + HBM_ - 1) / HBM_, nbn = g.N / HBN_;
+  int bid = blockIdx.x;
+  {
+    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
+  constexpr int CH = 8;
+  const int per_chunk = CH * nbn;
+  const int chunk = bid / per_chunk, rc = bid % per_chunk;
+  const int rows = (nbm - chunk * CH) < CH ? (nbm - chunk * CH) : CH;
+  const int sc = rc / (rows * GN), r2 = rc % (rows * GN);
+  const int bm = chunk * CH + r2 / GN, bn = sc * GN + r2 % GN;
+  const int m0 = bm * HBM_, n0 = bn * HBN_;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  // LDS-DMA pieces: instruction j of wave w fills rows [64 j + 8 w, +8) of A (or W); lane -> (row = lane >> 3, LDS chunk =
+  // lane & 7), source chunk (lane & 7) ^ (row & 7).  Half-tile h = 0,1: A rows [128 h, +128) (j = 2h, 2h + 1); h = 2,3: W.
+  const int srow = wave * 8 + (lane >> 3);
+  const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
+  uint32_t aoff[4], woff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int m = m0 + 64 * j + srow;
+    m = m < g.M ? m : g.M - 1;
+    aoff[j] = (uint32_t)m * (uint32_t)g.K + sch;
+    woff[j] = (uint32_t)(n0 + 64 * j + srow) * (uint32_t)g.K + sch;
+  }
+  const int KT = g.K / 64;
+  auto stage = [&](auto hc, int kt) {              // half-tile hc of K-tile kt (clamped) into buffer kt & 1
+    constexpr int h = decltype(hc)::value;
+    const int buf = kt & 1, kc = PEEL ? kt : (kt < KT ? kt : KT - 1);
+    char* base = smem + buf * 65536 + wave * 1024 + (h >> 1) * 32768;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = 2 * (h & 1) + u;
+      const T* src = (h < 2 ? A + aoff[j] : W + woff[j]) + kc * 64;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][8];   // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw0 = ((fq) ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
+  const int a_off = (wm * 128 + fr) * 128, w_off = 32768 + (wn * 64 + fr) * 128;
+  X8 fa0[8], fa1[8], fw0[4], fw1[4];               // [tile * 2 + kk]
+  auto rd_a = [&](X8 (&f)[8], const char* lb, int ah) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f[2 * t] = *reinterpret_cast<const X8*>(lb + a_off + (4 * ah + t) * 2048 + sw0);
+      f[2 * t + 1] = *reinterpret_cast<const X8*>(lb + a_off + (4 * ah + t) * 2048 + sw1);
+    }
+  };
+  auto rd_w = [&](X8 (&f)[4], const char* lb, int wh) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f[2 * t] = *reinterpret_cast<const X8*>(lb + w_off + (2 * wh + t) * 2048 + sw0);
+      f[2 * t + 1] = *reinterpret_cast<const X8*>(lb + w_off + (2 * wh + t) * 2048 + sw1);
+    }
+  };
+  auto quad = [&](const X8 (&fa)[8], const X8 (&fw)[4], auto ahc, auto whc) {   // 16 MFMAs, 8 accumulators x 2 k-chunks
+    constexpr int ah = decltype(ahc)::value, wh = decltype(whc)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[2 * wh + nt][4 * ah + mt] = Op::mma16(fw[2 * nt + kk], fa[2 * mt + kk], acc[2 * wh + nt][4 * ah + mt]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  using H2 = std::integral_constant<int, 2>;
+  using H3 = std::integral_constant<int, 3>;
+#define HVLA_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // ---- prologue: tile 0 complete in buffer 0, the A halves of tile 1 in flight in buffer 1
+  stage(H0{}, 0); stage(H1{}, 0); stage(H2{}, 0); stage(H3{}, 0);
+  if (KT > 1 || !PEEL) {
+    stage(H0{}, 1); stage(H1{}, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  HVLA_BAR();
+  if (wm == 1) HVLA_BAR();                          // waves 4-7 run half a phase behind
+  // one K-tile = four phases.  S1: tile kt+1 exists (stage its W halves in phases 1, 2); S2: tile kt+2 exists (stage its A
+  // halves in phases 3, 4).  The last two K-tiles are peeled so that nothing is staged past the end and the phase-4 wait
+  // stays an immediate: vmcnt(4) with both A halves of tile kt+2 in flight, vmcnt(0) without.
+  auto ktile = [&](int kt, auto s1c, auto s2c) {
+    constexpr bool S1 = decltype(s1c)::value, S2 = decltype(s2c)::value;
+    const char* lb = smem + (kt & 1) * 65536;
+    // phase 1: fragments A0, W0
+    rd_w(fw0, lb, 0);
+    rd_a(fa0, lb, 0);
+    if constexpr (S1) stage(H2{}, kt + 1);
+    HVLA_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    quad(fa0, fw0, H0{}, H0{});
+    HVLA_BAR();
+    // phase 2: fragments A1, W1 -- the last reads of this buffer, retired BEFORE the barrier: the other wave row restages
+    // the buffer right after it
+    rd_w(fw1, lb, 1);
+    rd_a(fa1, lb, 1);
+    if constexpr (S1) stage(H3{}, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    HVLA_BAR();
+    quad(fa0, fw1, H0{}, H1{});
+    HVLA_BAR();
+    // phase 3
+    if constexpr (S2) stage(H0{}, kt + 2);
+    HVLA_BAR();
+    quad(fa1, fw1, H1{}, H1{});
+    HVLA_BAR();
+    // phase 4: tile kt+1 must have landed (its last piece was issued in phase 2)
+    if constexpr (S2) stage(H1{}, kt + 2);
+    if constexpr (S2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (S1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HVLA_BAR();
+    quad(fa1, fw0, H1{}, H0{});
+    HVLA_BAR();
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  if constexpr (PEEL) {
+    int kt = 0;
+    for (; kt + 2 < KT; ++kt) ktile(kt, Yes{}, Yes{});
+    if (kt + 1 < KT) { ktile(kt, Yes{}, No{}); ++kt; }
+    ktile(kt, No{}, No{});
+  } else {      // diagnostics: stage past the end (clamped re-loads of the last tile), one loop body
+    for (int kt = 0; kt < KT; ++kt) ktile(kt, Yes{}, Yes{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (wm == 0) HVLA_BAR();                          // same number of barriers in both wave rows
+#undef HVLA_BAR
+  gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+}
+
 // In-place residual epilogue of the ring kernel with the x tile PREFETCHED by LDS-DMA.  Loading x through
 // registers costs ~18 us per 256x256 tile (32 dependent 16-B round trips per lane interleaved with stores
 // that may alias them); here the tile comes in as four 64-row quarters of 64 KB through the (now idle) LDS
@@ -935,10 +1099,13 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm256_kernel<Op, EPI_RES>))
     SETA((gemm256r_kernel<Op, EPI_PATCH>)) SETA((gemm256r_kernel<Op, EPI_QKV>)) SETA((gemm256r_kernel<Op, EPI_GELU>))
     SETA((gemm256r_kernel<Op, EPI_RES>))
+    SETA((gemm256p_kernel<Op, EPI_PATCH>)) SETA((gemm256p_kernel<Op, EPI_QKV>)) SETA((gemm256p_kernel<Op, EPI_GELU>))
+    SETA((gemm256p_kernel<Op, EPI_RES>))
 #undef SETA
     attr = true;
   }
-  static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" force the older kernels
+  static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" | "phase" | "ring" select a kernel
+  static const bool phased = !(gsel && !strcmp(gsel, "ring"));
   // split-K of the tail-round tiles of the residual GEMMs is opt-in: it buys < 1 % of the step, and its f32 atomic adds make
   // the one episode that owns those rows run-to-run different by up to 2e-3 in its tokens (tools/tail_probe.py)
   static const bool nosplit = getenv("HVLA_SPLIT_TAIL") == nullptr;
@@ -949,13 +1116,15 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
   }
-  auto gemm = [&](auto kern, auto kern256, auto kern256r, const void* A, const void* Wt, int Mm, int N, int K,
+  auto gemm = [&](auto kern, auto kern256, auto kern256r, auto kern256p, const void* A, const void* Wt, int Mm, int N, int K,
                   const float* bias, const float* aux, void* out, int qcols, bool is_res = false) {
     GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
     a.no_dma_epilogue = no_dma_epi;
     const bool big = N % HBN_ == 0 && Mm >= 1024 && !(gsel && !strcmp(gsel, "128"));
     const bool fits32 = (size_t)Mm * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
-    if (big && K >= 256 && fits32 && !(gsel && !strcmp(gsel, "simple"))) {
+    if (big && K >= 256 && fits32 && phased) {
+      hipLaunchKernelGGL(kern256p, dim3(((Mm + HBM_ - 1) / HBM_) * (N / HBN_)), dim3(512), 131072, st, a);
+    } else if (big && K >= 256 && fits32 && !(gsel && !strcmp(gsel, "simple"))) {
       int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
       // tail-round fix (in-place residual epilogue only): when a few tiles spill into an extra round on the
       // 256 CUs, split those along K over otherwise idle CUs
@@ -989,7 +1158,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     hipLaunchKernelGGL(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
                        g.image_size, g.patch, g.grid(), Kp);
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * E + 255) / 256), dim3(256), 0, st, ws.x, w.pos, B, S, E);
-    gemm(gemm_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0);
+    gemm(gemm_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0);
   }
   pf.end(0, st);
   const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
@@ -1001,24 +1170,24 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                        L.ln1_b, M, E, S);
     pf.end(1, st);
     pf.begin(2, st);
-    gemm(gemm_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
+    gemm(gemm_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
     pf.end(2, st);
     pf.begin(3, st);
     hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H);
     pf.end(3, st);
     pf.begin(4, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
     pf.end(4, st);
     pf.begin(1, st);
     hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln2_s,
                        L.ln2_b, M, E, S);
     pf.end(1, st);
     pf.begin(5, st);
-    gemm(gemm_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0);
+    gemm(gemm_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0);
     pf.end(5, st);
     pf.begin(6, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
     pf.end(6, st);
   }
   pf.begin(1, st);
@@ -1062,6 +1231,11 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
 #define L256R(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E>), dim3(nb256), dim3(512), 131072, st, a)
       if (epi == EPI_QKV) L256R(EPI_QKV); else if (epi == EPI_GELU) L256R(EPI_GELU); else L256R(EPI_RES);
 #undef L256R
+    } else if (variant == 9 || variant == 10) {
+#define L256P(E) do { if (variant == 9) hipLaunchKernelGGL((gemm256p_kernel<Op, E, true>), dim3(nb256), dim3(512), 131072, st, a); \
+                      else hipLaunchKernelGGL((gemm256p_kernel<Op, E, false>), dim3(nb256), dim3(512), 131072, st, a); } while (0)
+      if (epi == EPI_QKV) L256P(EPI_QKV); else if (epi == EPI_GELU) L256P(EPI_GELU); else L256P(EPI_RES);
+#undef L256P
     } else if (variant == 4) {
 #define L256R4(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E, 2, 0, 5>), dim3(nb256), dim3(512), 163840, st, a)
       if (epi == EPI_QKV) L256R4(EPI_QKV); else if (epi == EPI_GELU) L256R4(EPI_GELU); else L256R4(EPI_RES);
@@ -1079,6 +1253,12 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_GELU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_RES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 0, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU, 2, 0, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES, 2, 0, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
