@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 
 // ------------------------------------------------------------------------------------------------
 // 256x256x64 tile, 8 waves, FOUR PHASES per K-tile with the two wave rows running half a phase apart (guide §5 "256^2
-// 8-phase template": counted vmcnt, raw s_barrier, s_setprio around the MFMA clusters, staggered wave groups).
+// 8-phase template": counted vmcnt, raw s_barrier, staggered wave groups).
 //   * a phase = { ds_read fragments | issue one 16 KB half-tile of LDS-DMA } barrier { 16 MFMAs = one quadrant of the
 //     wave's 128x64 tile over K = 64 } barrier.  Waves 4-7 execute one extra barrier up front, so while waves 0-3 are in
 //     their MFMA cluster waves 4-7 (the other wave on each SIMD) read LDS / issue DMA, and vice versa: the matrix pipe and
@@ -388,7 +388,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 //     t+1 has landed, the two A halves of tile t+2 stay in flight across the barriers.
 //   * the last two K-tiles are peeled (nothing is staged past the end, the wait constants stay immediates).
 // LDS image and swizzle are those of gemm256_kernel (128-byte rows, chunk ^= row & 7 on the source and on the read).
-template <typename Op, int EPI, bool PEEL = true>
+// FL (diagnostics): 1 no stagger, 2 s_setprio(1) around the MFMA clusters (measured 10 % SLOWER here, off by default),
+// 4 no DMA in the loop, 8 no MFMA, 16 no fragment reads in the loop
+template <typename Op, int EPI, bool PEEL = true, int FL = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   using T = typename Op::elem;
   using X8 = typename Op::x8;
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   const int KT = g.K / 64;
   auto stage = [&](auto hc, int kt) {              // half-tile hc of K-tile kt (clamped) into buffer kt & 1
     constexpr int h = decltype(hc)::value;
+    if ((FL & 4) && kt > 1) return;
     const int buf = kt & 1, kc = PEEL ? kt : (kt < KT ? kt : KT - 1);
     char* base = smem + buf * 65536 + wave * 1024 + (h >> 1) * 32768;
 #pragma unroll
@@ -447,6 +450,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   const int a_off = (wm * 128 + fr) * 128, w_off = 32768 + (wn * 64 + fr) * 128;
   X8 fa0[8], fa1[8], fw0[4], fw1[4];               // [tile * 2 + kk]
   auto rd_a = [&](X8 (&f)[8], const char* lb, int ah) {
+    if ((FL & 16) && lb != smem) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f[2 * t] = *reinterpret_cast<const X8*>(lb + a_off + (4 * ah + t) * 2048 + sw0);
@@ -454,6 +458,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     }
   };
   auto rd_w = [&](X8 (&f)[4], const char* lb, int wh) {
+    if ((FL & 16) && lb != smem) return;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f[2 * t] = *reinterpret_cast<const X8*>(lb + w_off + (2 * wh + t) * 2048 + sw0);
@@ -462,7 +467,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   };
   auto quad = [&](const X8 (&fa)[8], const X8 (&fw)[4], auto ahc, auto whc) {   // 16 MFMAs, 8 accumulators x 2 k-chunks
     constexpr int ah = decltype(ahc)::value, wh = decltype(whc)::value;
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (FL & 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fw[i]));
+      return;
+    }
+    if constexpr (FL & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
           acc[2 * wh + nt][4 * ah + mt] = Op::mma16(fw[2 * nt + kk], fa[2 * mt + kk], acc[2 * wh + nt][4 * ah + mt]);
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (FL & 2) __builtin_amdgcn_s_setprio(0);
   };
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   HVLA_BAR();
-  if (wm == 1) HVLA_BAR();                          // waves 4-7 run half a phase behind
+  if (wm == 1 && !(FL & 1)) HVLA_BAR();             // waves 4-7 run half a phase behind
   // one K-tile = four phases.  S1: tile kt+1 exists (stage its W halves in phases 1, 2); S2: tile kt+2 exists (stage its A
   // halves in phases 3, 4).  The last two K-tiles are peeled so that nothing is staged past the end and the phase-4 wait
   // stays an immediate: vmcnt(4) with both A halves of tile kt+2 in flight, vmcnt(0) without.
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     for (int kt = 0; kt < KT; ++kt) ktile(kt, Yes{}, Yes{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  if (wm == 0) HVLA_BAR();                          // same number of barriers in both wave rows
+  if (wm == 0 && !(FL & 1)) HVLA_BAR();             // same number of barriers in both wave rows
 #undef HVLA_BAR
   gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
 }
@@ -1236,6 +1248,12 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
                       else hipLaunchKernelGGL((gemm256p_kernel<Op, E, false>), dim3(nb256), dim3(512), 131072, st, a); } while (0)
       if (epi == EPI_QKV) L256P(EPI_QKV); else if (epi == EPI_GELU) L256P(EPI_GELU); else L256P(EPI_RES);
 #undef L256P
+    } else if (variant >= 11 && variant <= 15) {
+      if (variant == 11) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 1>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 12) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 2>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 13) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 4>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 14) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 8>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 15) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 16>), dim3(nb256), dim3(512), 131072, st, a);
     } else if (variant == 4) {
 #define L256R4(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E, 2, 0, 5>), dim3(nb256), dim3(512), 163840, st, a)
       if (epi == EPI_QKV) L256R4(EPI_QKV); else if (epi == EPI_GELU) L256R4(EPI_GELU); else L256R4(EPI_RES);
@@ -1257,6 +1275,11 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_GELU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_RES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 0, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
