@@ -261,7 +261,7 @@ def main():
         vals = {}
         for nm in ("fetch", "write"):
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_pmc_{nm}_size_by_kernel.csv"))):
-                if "gemm256r_kernel<hvla::OpF16, 2" in row["kernel"]:
+                if "gemm256p_kernel<hvla::OpF16, 2" in row["kernel"]:
                     vals[nm] = float(row["mean"]) * 1024.0
         if B == 256 and a.enc_dtype == "f16" and a.encoder == "base" and a.streams == 1 and len(vals) == 2:
             traffic = int(2 * vals["fetch"] + vals["write"])
@@ -289,7 +289,7 @@ def main():
                                if ens is not None else "not in the step"},
         "latency_samples": len(lat),
         "p50_step_latency_ms": round(float(np.median(lat)), 4),
-        "roofline": {"bound": "mfma", "kernel": f"gemm256r_kernel<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",
+        "roofline": {"bound": "mfma", "kernel": f"gemm256p_kernel<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",
                      "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_unit": "bytes/launch (HBM-side, PMC: 2*FETCH_SIZE+WRITE_SIZE; algorithmic 510 MB)",

@@ -12,7 +12,7 @@ python bench.py --finetune --train-encoder --batch 32 --steps 10 --warmup 3 > $P
 python bench.py --finetune --batch 32 --steps 10 --warmup 3 > $P/r1_finetune_b32_frozen_encoder.json 2>/dev/null
 python bench.py --finetune --batch 256 --steps 10 --warmup 3 > $P/r1_finetune_b256_frozen_encoder.json 2>/dev/null
 python tools/blas_ref_bench.py > $P/r1_vendor_gemm_reference.txt 2>/dev/null
-python tools/gemm_bench.py 256 > $P/r1_gemm_isolated.txt 2>/dev/null
+HVLA_VARIANTS=5,9 python tools/gemm_bench.py 256 > $P/r1_gemm_isolated.txt 2>/dev/null
 python tools/bgemm_bench.py > $P/r1_train_gemm_isolated.txt 2>/dev/null
 python tools/determinism_probe.py > $P/r1_determinism.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
