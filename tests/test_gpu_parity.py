@@ -500,3 +500,22 @@ def test_two_stream_step_gives_the_same_bytes():
             np.testing.assert_array_equal(act.cpu().numpy(), outs[0][0])
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_every_stage_is_run_to_run_deterministic(full):
+    """Context embedding, generated weights, encoder tokens and actions: 25 repetitions on identical inputs, bit-identical."""
+    from hypervla import synthetic as syn
+    m, g, B = full["model"], full["g"], 8
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    ref = None
+    for _ in range(25):
+        w, _, _ = m.create_tasks(instruction_dict=ins, initial_state=st)
+        theta, ctx = w.export()
+        tok = m.encode_images(im)
+        a, l = m.policy_from_tokens(tok, w)
+        cur = [t.clone() for t in (ctx, theta, tok, a, l)]
+        if ref is None:
+            ref = cur
+        else:
+            for name, x, y in zip(("ctx", "theta", "tokens", "actions", "logits"), cur, ref):
+                assert torch.equal(x, y), name
