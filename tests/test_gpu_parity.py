@@ -199,6 +199,18 @@ def test_inference_wrapper_episode(full):
     for t in range(3):
         raw, act, img, (desc, task), dt = wr.step(full["im"][t % 4, 0])
         assert raw.shape == (7,) and act.shape == (7,) and act[-1] in (-1.0, 1.0) and dt > 0
+    # raw camera frames: device-side lanczos3 resize + sqrt(0.9) crop, initial-image embedding on the device, then a step
+    from oracle import hvla_ref_np as onp
+    cam = np.random.default_rng(3).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    wc = InferenceWrapper(m, policy_setup="widowx_bridge", horizon=1, pred_action_horizon=4, image_size=224, crop=True)
+    st_dev = wc.initial_state_from_image(cam)
+    want = onp.preprocess_image(cam, 224, crop=True)
+    d = np.abs(st_dev["image_primary"].astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert tuple(st_dev["patch_embeddings"].shape) == (1, g.patches + 1, g.enc_dim)
+    wc.reset("put the spoon on the towel", ins1, st_dev)
+    raw, act, img, _, _ = wc.step(cam)
+    assert img.shape == (224, 224, 3) and np.isfinite(raw).all() and np.abs(raw[:6]).max() <= 5 * 0.5 + 1.0
 
 
 def test_hipgraph_replay_matches_eager(mid):
