@@ -259,6 +259,19 @@ def test_bf16_encoder_option(mid):
     assert np.abs(act[..., :6] - mid["act"][..., :6]).mean() <= 8e-3
 
 
+def test_bf16_encoder_full_geometry(full):
+    """The bf16 instantiation of the production (256x256, four-phase) GEMM at the README geometry against the golden
+    actions: same structure as fp16, operand rounding 8x coarser."""
+    from hypervla.model import HyperVLA
+    z, B = full["z"], full["B"]
+    m = HyperVLA.from_synthetic(full["g"], max_batch=B, enc_dtype="bf16")
+    w, tasks, _ = m.create_tasks(instruction_dict=full["ins"], initial_state=full["st"])
+    act, _ = m.sample_actions(full["im"], full["ins"], tasks, np.ones((B, 1)), base_params=w)
+    d = np.abs(np.asarray(act)[..., :6] - z["actions"][..., :6])
+    print("bf16 encoder, README geometry: action MAE", d.mean(), "max", d.max())
+    assert 1e-4 < d.mean() <= 1e-2
+
+
 def test_action_loss_matches_oracle(mid):
     """hvla_loss (A13 forward): per-sample 6*masked-MSE + masked BCE on the HIP path's own outputs."""
     from hypervla import synthetic as syn
