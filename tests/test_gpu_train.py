@@ -257,3 +257,61 @@ def test_full_geometry_gradient_is_the_mean_of_per_sample_gradients():
     acc /= B
     scale = float(big.abs().max())
     assert float((acc - big).abs().max()) <= 2e-4 * scale, float((acc - big).abs().max()) / scale
+
+
+def _dp_worker(rank, world, port, out_path):
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # one GPU on the test box: gloo moves the CUDA tensor
+    from hypervla import synthetic as syn
+    from hypervla.config import MID
+    from hypervla.dp import episode_range
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner
+    g, total = MID, 4
+    lo, hi = episode_range(total, world, rank)
+    sl = slice(lo, hi)
+    model = HyperVLA.from_synthetic(g, max_batch=hi - lo)
+    ins, st, im = syn.synthetic_instructions(total, g), syn.synthetic_initial_state(total, g), syn.synthetic_images(total, g)
+    batch = syn.synthetic_action_batch(total, g)
+    batch["timestep_pad_mask"][:] = True
+    ft = FineTuner(model, hi - lo, train_encoder=True)
+    li = ins["language_instruction"]
+    ft.step({"language_instruction": {k: np.asarray(v)[sl] for k, v in li.items()}}, {"patch_embeddings": st["patch_embeddings"][sl]},
+            im[sl], {k: v[sl] for k, v in batch.items()}, lr=1e-3, base_lr=1e-4)
+    if rank == 0:
+        np.save(out_path, np.stack([ft.params.cpu().numpy(), ft.grads.cpu().numpy()]))     # grads: after the all-reduce
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_data_parallel_step_equals_the_big_batch_step(tmp_path):
+    """Config 5's data parallelism: two ranks with half the samples each, gradient all-reduce (mean) between
+    hvla_train_step and hvla_train_apply (`pmean`, scripts/train.py:460) == one process with all the samples."""
+    import torch.multiprocessing as mp
+    from hypervla import synthetic as syn
+    from hypervla.config import MID
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner
+    out = str(tmp_path / "rank0.npy")
+    mp.spawn(_dp_worker, args=(2, 29533, out), nprocs=2, join=True)
+    g, total = MID, 4
+    model = HyperVLA.from_synthetic(g, max_batch=total)
+    ins, st, im = syn.synthetic_instructions(total, g), syn.synthetic_initial_state(total, g), syn.synthetic_images(total, g)
+    batch = syn.synthetic_action_batch(total, g)
+    batch["timestep_pad_mask"][:] = True
+    ft = FineTuner(model, total, train_encoder=True)
+    before = ft.params.cpu().numpy().copy()
+    ft.step(ins, st, im, batch, lr=1e-3, base_lr=1e-4)
+    single, gsingle = ft.params.cpu().numpy(), ft.grads.cpu().numpy()
+    dp, gdp = np.load(out)
+    gmax = np.abs(gsingle).max()
+    assert np.abs(gdp - gsingle).max() <= 2e-4 * gmax, np.abs(gdp - gsingle).max() / gmax
+    # Adam's first step is sign-like (lr * g / (|g| + eps)): compare the parameters where the gradient is not ~0
+    big = np.abs(gsingle) > 1e-4 * gmax
+    moved = np.abs(single - before)[big].max()
+    assert moved > 0 and np.abs(dp - single)[big].max() <= 1e-2 * moved, (np.abs(dp - single)[big].max(), moved)
