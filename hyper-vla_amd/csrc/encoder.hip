@@ -1118,6 +1118,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   }
   static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" | "phase" | "ring" select a kernel
   static const bool phased = !(gsel && !strcmp(gsel, "ring"));
+  static const bool nopeel = getenv("HVLA_NO_PEEL") != nullptr;
   // split-K of the tail-round tiles of the residual GEMMs is opt-in: it buys < 1 % of the step, and its f32 atomic adds make
   // the one episode that owns those rows run-to-run different by up to 2e-3 in its tokens (tools/tail_probe.py)
   static const bool nosplit = getenv("HVLA_SPLIT_TAIL") == nullptr;
@@ -1129,13 +1130,34 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
   }
   auto gemm = [&](auto kern, auto kern256, auto kern256r, auto kern256p, const void* A, const void* Wt, int Mm, int N, int K,
-                  const float* bias, const float* aux, void* out, int qcols, bool is_res = false) {
+                  const float* bias, const float* aux, void* out, int qcols, bool is_res = false, bool peel = true) {
     GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
     a.no_dma_epilogue = no_dma_epi;
     const bool big = N % HBN_ == 0 && Mm >= 1024 && !(gsel && !strcmp(gsel, "128"));
     const bool fits32 = (size_t)Mm * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
     if (big && K >= 256 && fits32 && phased) {
-      hipLaunchKernelGGL(kern256p, dim3(((Mm + HBM_ - 1) / HBM_) * (N / HBN_)), dim3(512), 131072, st, a);
+      const int nbn = N / HBN_;
+      int nbm = (Mm + HBM_ - 1) / HBM_;
+      // One workgroup per CU: the grid runs in rounds of `ncu` tiles, and B x 257 tokens leave a handful of tiles
+      // (257 = 256 + 1 M-tiles) that start an extra round (launch time steps with ceil(tiles / ncu): fc2 85 us per round).
+      // Peel the last r M-tile rows off so that the main grid is a whole number of rounds and give them to the 128x128
+      // kernel (four times the workgroups per tile, same k order and MFMA, so the same bits) right behind it.  Worth 1.2 %
+      // of the step (fc2 -3 %, out-proj -4 %): the small kernel is latency-bound (48 K-steps for fc2), so most of the round
+      // comes back as its run time.
+      const int rem = (nbm * nbn) % ncu, r = (rem + nbn - 1) / nbn;
+      if (peel && !nopeel && rem > 0 && r * 8 <= nbm && ((nbm - r) * nbn) % ncu == 0 && Mm % HBM_ == 0) {
+        const int m_main = (nbm - r) * HBM_, m_tail = Mm - m_main;
+        GemmArgs t = a;
+        t.A = reinterpret_cast<const T*>(A) + (size_t)m_main * K;
+        t.out = is_res ? static_cast<void*>(reinterpret_cast<float*>(out) + (size_t)m_main * N)
+                       : static_cast<void*>(reinterpret_cast<T*>(out) + (size_t)m_main * N);
+        t.M = m_tail;
+        a.M = m_main;
+        hipLaunchKernelGGL(kern256p, dim3((nbm - r) * nbn), dim3(512), 131072, st, a);
+        hipLaunchKernelGGL(kern, dim3(((m_tail + GBM - 1) / GBM) * (N / GBN)), dim3(256), gsm, st, t);
+      } else {
+        hipLaunchKernelGGL(kern256p, dim3(nbm * nbn), dim3(512), 131072, st, a);
+      }
     } else if (big && K >= 256 && fits32 && !(gsel && !strcmp(gsel, "simple"))) {
       int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
       // tail-round fix (in-place residual epilogue only): when a few tiles spill into an extra round on the
@@ -1170,7 +1192,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     hipLaunchKernelGGL(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
                        g.image_size, g.patch, g.grid(), Kp);
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * E + 255) / 256), dim3(256), 0, st, ws.x, w.pos, B, S, E);
-    gemm(gemm_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0);
+    gemm(gemm_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0, false, false);
   }
   pf.end(0, st);
   const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
