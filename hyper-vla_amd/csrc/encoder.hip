@@ -84,6 +84,9 @@ struct GemmArgs {
   int split_from = 0;    // RES only: logical tiles >= split_from are split along K into split_parts
   int split_parts = 0;   // workgroups that accumulate into x with f32 atomics (tail-round fix)
   int no_dma_epilogue = 0;   // diagnostics: residual tile through registers instead of LDS-DMA
+  int stagger = 0;           // gemm256p: first-round workgroups of XCD group g start g * stagger / groups ticks (10 ns) late
+  int stagger_groups = 2;
+  int first_round = 0;       // workgroups of the first round (= CUs)
 };
 
 // Epilogue shared by both GEMM kernels.  acc[nt][mt]: lane holds column m = m_base + 16 mt + fr and rows
@@ -171,6 +174,93 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MT], const 
   }
 }
 
+// Row-major epilogue of the production kernels (gemm256p_kernel, gemm_kernel).  Those run the MFMA with the activation
+// fragment as the first operand and stage W so that the LDS row 16 nt + c of a wave's 64 columns holds global column
+// 4 c + nt (wperm() below): lane (fr, fq) then owns, for each of its rows m = m_base + 16 mt + 4 fq + r, the FOUR
+// CONSECUTIVE columns n_base + 4 fr + {0..3} (one from each accumulator tile nt).  A store instruction therefore covers
+// 4 rows x 64 consecutive columns -- four full 128-B lines of a 16-bit output, eight of an f32 one -- instead of 64
+// scattered 8-B pieces (measured on the QKV shape: the old per-lane-column layout spent 8.6 us of a 24 us tile in its
+// epilogue even on an otherwise idle chip; the memory pipe handles one line per cycle, not one instruction).
+__device__ __forceinline__ int wperm(int rho) { return (rho & ~63) + 4 * (rho & 15) + ((rho >> 4) & 3); }
+
+template <typename Op, int EPI, int MT, bool FULL>
+__device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
+                                                        int fr, int fq) {
+  using T = typename Op::elem;
+  const int n = n_base + 4 * fr;
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+  f32x4 l4 = f32x4{1.f, 1.f, 1.f, 1.f};
+  if constexpr (EPI == EPI_RES) l4 = *reinterpret_cast<const f32x4*>(g.aux + n);
+  const float q = EPI == EPI_PATCH ? g.qscale : ((EPI == EPI_QKV && n_base < g.qcols) ? g.qscale : 1.f);
+  // FULL (every row of the wave tile exists): straight-line code, 32-bit element offsets from the uniform base.  With the
+  // per-row `m < M` branches the compiler has to put an s_waitcnt vmcnt(0) into every predicated block (for the bias load),
+  // which also waits for the previous STORE: 32 serialised store round trips per wave, 6.5 us per 256x256 tile.
+  constexpr int RB = EPI == EPI_RES ? 4 : 2;        // m-tiles per batch: residual loads of a batch are issued together
+#pragma unroll
+  for (int mp = 0; mp < MT; mp += RB) {
+    f32x4 xin[RB][4];
+    uint32_t off[RB][4];
+    bool ok[RB][4];
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m_base + (mp + u) * 16 + 4 * fq + r;
+        ok[u][r] = FULL || m < g.M;
+        off[u][r] = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+        if constexpr (EPI == EPI_PATCH) {
+          const int prow = 1 + (m % g.P);
+          off[u][r] = (uint32_t)((m / g.P) * g.S + prow) * (uint32_t)g.N + (uint32_t)n;
+          if (ok[u][r]) xin[u][r] = *reinterpret_cast<const f32x4*>(g.aux + (uint32_t)prow * (uint32_t)g.N + (uint32_t)n);
+        }
+        if constexpr (EPI == EPI_RES) {
+          if (ok[u][r]) xin[u][r] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.out) + off[u][r]);
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      f32x4 t[4];                                    // [column c] over the four rows r: the accumulators' own register pairs
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if constexpr (EPI == EPI_PATCH) t[c] = acc[c][mp + u] * q + b4[c];      // patch weights are stored x256 (16-bit range)
+        else t[c] = acc[c][mp + u] + b4[c];
+        if constexpr (EPI == EPI_QKV) t[c] *= q;
+        if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[c][r] = gelu_erf(t[c][r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (!ok[u][r]) continue;
+        if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) {
+          typename Op::x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = (T)t[c][r];
+          *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]) = o;
+        } else if constexpr (EPI == EPI_RES) {
+          f32x4 x = xin[u][r];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x[c] = fmaf(t[c][r], l4[c], x[c]);
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + off[u][r]) = x;
+        } else {
+          f32x4 x = xin[u][r];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x[c] += t[c][r];
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + off[u][r]) = x;
+        }
+      }
+    }
+  }
+}
+
+template <typename Op, int EPI, int MT>
+__device__ __forceinline__ void gemm_epilogue_rows(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
+                                                   int fr, int fq) {
+  if (m_base + 16 * MT <= g.M) gemm_epilogue_rows_impl<Op, EPI, MT, true>(acc, g, m_base, n_base, fr, fq);
+  else gemm_epilogue_rows_impl<Op, EPI, MT, false>(acc, g, m_base, n_base, fr, fq);
+}
+
 // split-K tail tiles of a RES GEMM: x += (acc + [part 0] bias) * layerscale with f32 atomics
 // (global_atomic_add_f32; order-dependent in the last bits, only the <= 1 % of rows of the tail tiles)
 template <int NT, int MT>
@@ -226,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     int m = m0 + lrow + 32 * i;
     m = m < g.M ? m : g.M - 1;
     ap[i] = A + (size_t)m * g.K + lch * 8;
-    wp[i] = W + (size_t)(n0 + lrow + 32 * i) * g.K + lch * 8;
+    wp[i] = W + (size_t)(n0 + wperm(lrow + 32 * i)) * g.K + lch * 8;   // LDS row -> column permutation of the epilogue
   }
   X8 ra[4], rw[4];
   auto gload = [&](int kt) {
@@ -244,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
   };
 
-  f32x4 acc[4][4];   // [n-tile][m-tile]: D = W-tile(16 n rows) x A-tile^T (16 m cols)
+  f32x4 acc[4][4];   // [n-tile][m-tile]: D = A-tile (16 m rows) x W-tile^T (16 n cols)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -271,13 +361,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = Op::mma16(fw[nt], fa[mt], acc[nt][mt]);
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = Op::mma16(fa[mt], fw[nt], acc[nt][mt]);
     }
     if (kt + 1 < KT) sstore(buf ^ 1);
     __syncthreads();
   }
 
-  gemm_epilogue<Op, EPI, 4, 4>(acc, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
+  gemm_epilogue_rows<Op, EPI, 4>(acc, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 //   * the last two K-tiles are peeled (nothing is staged past the end, the wait constants stay immediates).
 // LDS image and swizzle are those of gemm256_kernel (128-byte rows, chunk ^= row & 7 on the source and on the read).
 // FL (diagnostics): 1 no stagger, 2 s_setprio(1) around the MFMA clusters (measured 10 % SLOWER here, off by default),
-// 4 no DMA in the loop, 8 no MFMA, 16 no fragment reads in the loop
+// 4 no DMA in the loop, 8 no MFMA, 16 no fragment reads in the loop, 32 no epilogue
 template <typename Op, int EPI, bool PEEL = true, int FL = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   using T = typename Op::elem;
@@ -424,9 +514,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     int m = m0 + 64 * j + srow;
     m = m < g.M ? m : g.M - 1;
     aoff[j] = (uint32_t)m * (uint32_t)g.K + sch;
-    woff[j] = (uint32_t)(n0 + 64 * j + srow) * (uint32_t)g.K + sch;
+    woff[j] = (uint32_t)(n0 + ((FL & 64) ? 64 * j + srow : wperm(64 * j + srow))) * (uint32_t)g.K + sch;   // column permutation of the epilogue
   }
   const int KT = g.K / 64;
+  if (g.stagger > 0 && (int)blockIdx.x < g.first_round) {
+    const int grp = ((int)(blockIdx.x & 7) * g.stagger_groups) >> 3;
+    const long long wait = (long long)grp * g.stagger / g.stagger_groups;
+    const long long t0 = wall_clock64();
+    while ((long long)wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
   auto stage = [&](auto hc, int kt) {              // half-tile hc of K-tile kt (clamped) into buffer kt & 1
     constexpr int h = decltype(hc)::value;
     if ((FL & 4) && kt > 1) return;
@@ -481,7 +577,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-          acc[2 * wh + nt][4 * ah + mt] = Op::mma16(fw[2 * nt + kk], fa[2 * mt + kk], acc[2 * wh + nt][4 * ah + mt]);
+          if constexpr (FL & 64) acc[2 * wh + nt][4 * ah + mt] = Op::mma16(fw[2 * nt + kk], fa[2 * mt + kk], acc[2 * wh + nt][4 * ah + mt]);
+          else acc[2 * wh + nt][4 * ah + mt] = Op::mma16(fa[2 * mt + kk], fw[2 * nt + kk], acc[2 * wh + nt][4 * ah + mt]);
     if constexpr (FL & 2) __builtin_amdgcn_s_setprio(0);
   };
   using H0 = std::integral_constant<int, 0>;
@@ -548,7 +645,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   }
   if (wm == 0 && !(FL & 1)) HVLA_BAR();             // same number of barriers in both wave rows
 #undef HVLA_BAR
-  gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+  if constexpr (FL & 32) {                          // diagnostics: no epilogue (one lane keeps the accumulators alive)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345.678f) reinterpret_cast<float*>(g.out)[0] = s;
+    return;
+  }
+  if constexpr (FL & 64) { gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq); return; }
+  if constexpr (FL & 128) {                         // diagnostics: every CU stores into the first tile rows (stays in L2)
+    gemm_epilogue_rows<Op, EPI, 8>(acc, g, wm * 128, (blockIdx.x % (g.N / HBN_)) * HBN_ + wn * 64, fr, fq);
+    return;
+  }
+  gemm_epilogue_rows<Op, EPI, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
 }
 
 // In-place residual epilogue of the ring kernel with the x tile PREFETCHED by LDS-DMA.  Loading x through
@@ -1099,6 +1210,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   const int P = g.P(), S = g.S(), E = g.E, F = g.enc_mlp, H = g.enc_heads;
   const int Kp = 2 * ((g.patch * g.patch * 3 + 63) / 64 * 64);   // [a | a] x [W_hi | W_lo]
   const int M = B * S;
+  // the GEMM epilogues address their outputs with 32-bit element offsets
+  if ((size_t)M * (size_t)(F > 3 * E ? F : 3 * E) >= (1ull << 32)) return hipErrorInvalidValue;
   const size_t gsm = (size_t)2 * (GBM + GBN) * GLD * sizeof(T);
   static bool attr = false;
   if (!attr) {
@@ -1239,6 +1352,8 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st) {
   using Op = OpF16;
   GemmArgs a{A, W, M, N, K, bias, aux, out, 256, 257, epi == EPI_QKV ? N / 3 : 0, 0.125f};
+  if (const char* e = getenv("HVLA_STAGGER")) { a.stagger = atoi(e); a.first_round = 256; }
+  if (const char* e = getenv("HVLA_STAGGER_GROUPS")) a.stagger_groups = atoi(e);
   if (const char* e = getenv("HVLA_DBG_LDA")) a.lda = K + atoi(e);
   if (const char* e = getenv("HVLA_DBG_LDW")) a.ldw = K + atoi(e);
   hipEvent_t e0, e1;
@@ -1277,6 +1392,18 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
       if (variant == 13) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 4>), dim3(nb256), dim3(512), 131072, st, a);
       if (variant == 14) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 8>), dim3(nb256), dim3(512), 131072, st, a);
       if (variant == 15) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 16>), dim3(nb256), dim3(512), 131072, st, a);
+    } else if (variant >= 16 && variant <= 21) {
+      if (variant == 16) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 28>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 17) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 20>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 18) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 12>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 19) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 24>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 20) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 21>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 21) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 32>), dim3(nb256), dim3(512), 131072, st, a);
+    } else if (variant >= 22 && variant <= 25) {
+      if (variant == 22) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 64>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 23) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 128>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 24) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_GELU, true, 64>), dim3(nb256), dim3(512), 131072, st, a);
+      if (variant == 25) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_RES, true, 64>), dim3(nb256), dim3(512), 131072, st, a);
     } else if (variant == 4) {
 #define L256R4(E) hipLaunchKernelGGL((gemm256r_kernel<Op, E, 2, 0, 5>), dim3(nb256), dim3(512), 163840, st, a)
       if (epi == EPI_QKV) L256R4(EPI_QKV); else if (epi == EPI_GELU) L256R4(EPI_GELU); else L256R4(EPI_RES);
