@@ -195,7 +195,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
   // FULL (every row of the wave tile exists): straight-line code, 32-bit element offsets from the uniform base.  With the
   // per-row `m < M` branches the compiler has to put an s_waitcnt vmcnt(0) into every predicated block (for the bias load),
   // which also waits for the previous STORE: 32 serialised store round trips per wave, 6.5 us per 256x256 tile.
-  constexpr int RB = EPI == EPI_RES ? 4 : 2;        // m-tiles per batch: residual loads of a batch are issued together
+  constexpr int RB = MT < 2 ? 1 : (EPI == EPI_RES && MT >= 4 ? 4 : 2);   // m-tiles per batch: residual loads of a batch are issued together
 #pragma unroll
   for (int mp = 0; mp < MT; mp += RB) {
     f32x4 xin[RB][4];
@@ -368,6 +368,89 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   }
 
   gemm_epilogue_rows<Op, EPI, 4>(acc, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm64_kernel -- 64x64x64 tiles for SMALL row counts (the peeled tail rows of a big GEMM, B = 1..3): such a problem
+// is pure latency, so it is cut into many small workgroups (256 rows x 768 columns -> 48) and each keeps SNS - 1 = 5
+// K-tiles of LDS-DMA in flight (6 stages x 16 KB, counted vmcnt, one raw barrier per K-tile).  Four waves, wave w owns
+// rows [16 w, +16) x all 64 columns: 10 ds_read_b128 and 8 MFMAs per K-tile.  LDS image, swizzle, W-row permutation, MFMA
+// and k order are those of gemm256p_kernel, so a row gets the same bits whichever kernel computes it.
+constexpr int SBM = 64, SBN = 64, SNS = 6;
+template <typename Op, int EPI>
+__global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
+  using T = typename Op::elem;
+  using X8 = typename Op::x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // SNS x (A 8 KB | W 8 KB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbm = (g.M + SBM - 1) / SBM;
+  const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
+  const int m0 = bm * SBM, n0 = bn * SBN;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  // LDS-DMA pieces: instruction j = 0, 1 of wave w fills rows [32 j + 8 w, +8); lane -> (row = lane >> 3, LDS chunk = lane & 7),
+  // source chunk (lane & 7) ^ (row & 7)
+  const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
+  uint32_t aoff[2], woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rl = 32 * j + 8 * wave + (lane >> 3);
+    int m = m0 + rl;
+    m = m < g.M ? m : g.M - 1;
+    aoff[j] = (uint32_t)m * (uint32_t)g.K + sch;
+    woff[j] = (uint32_t)(n0 + wperm(rl)) * (uint32_t)g.K + sch;
+  }
+  const int KT = g.K / 64;
+  auto issue = [&](int kt) {
+    char* base = smem + (kt % SNS) * 16384 + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoff[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + j * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + woff[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + 8192 + j * 4096), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw0 = (fq ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
+  const int a_off = (wave * 16 + fr) * 128, w_off = 8192 + fr * 128;
+#pragma unroll
+  for (int s = 0; s < SNS - 1; ++s)
+    if (s < KT) issue(s);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int issued = kt + SNS - 1 < KT ? kt + SNS - 1 : KT;
+    switch (issued - kt - 1) {                       // K-tiles issued after tile kt may stay in flight (4 pieces each)
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                    // tile kt landed for every wave; everyone is done reading tile kt - 1
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + SNS - 1 < KT) issue(kt + SNS - 1);      // into the stage of tile kt - 1
+    const char* lb = smem + (kt % SNS) * 16384;
+    X8 fa[2], fw[4][2];
+    fa[0] = *reinterpret_cast<const X8*>(lb + a_off + sw0);
+    fa[1] = *reinterpret_cast<const X8*>(lb + a_off + sw1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      fw[nt][0] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw0);
+      fw[nt][1] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][0] = Op::mma16(fa[kk], fw[nt][kk], acc[nt][0]);
+  }
+  gemm_epilogue_rows<Op, EPI, 1>(acc, g, m0 + wave * 16, n0, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1226,12 +1309,15 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm256r_kernel<Op, EPI_RES>))
     SETA((gemm256p_kernel<Op, EPI_PATCH>)) SETA((gemm256p_kernel<Op, EPI_QKV>)) SETA((gemm256p_kernel<Op, EPI_GELU>))
     SETA((gemm256p_kernel<Op, EPI_RES>))
+    SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
+    SETA((gemm64_kernel<Op, EPI_RES>))
 #undef SETA
     attr = true;
   }
   static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" | "phase" | "ring" select a kernel
   static const bool phased = !(gsel && !strcmp(gsel, "ring"));
   static const bool nopeel = getenv("HVLA_NO_PEEL") != nullptr;
+  static const int g64_maxm = getenv("HVLA_G64_MAXM") ? atoi(getenv("HVLA_G64_MAXM")) : 2047;   // rows up to which the 64x64 kernel is used
   // split-K of the tail-round tiles of the residual GEMMs is opt-in: it buys < 1 % of the step, and its f32 atomic adds make
   // the one episode that owns those rows run-to-run different by up to 2e-3 in its tokens (tools/tail_probe.py)
   static const bool nosplit = getenv("HVLA_SPLIT_TAIL") == nullptr;
@@ -1242,11 +1328,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
   }
-  auto gemm = [&](auto kern, auto kern256, auto kern256r, auto kern256p, const void* A, const void* Wt, int Mm, int N, int K,
+  auto gemm = [&](auto kern, auto kern64, auto kern256, auto kern256r, auto kern256p, const void* A, const void* Wt, int Mm, int N, int K,
                   const float* bias, const float* aux, void* out, int qcols, bool is_res = false, bool peel = true) {
     GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
     a.no_dma_epilogue = no_dma_epi;
-    const bool big = N % HBN_ == 0 && Mm >= 1024 && !(gsel && !strcmp(gsel, "128"));
+    const bool big = N % HBN_ == 0 && Mm > g64_maxm && Mm >= 1024 && !(gsel && !strcmp(gsel, "128"));
     const bool fits32 = (size_t)Mm * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
     if (big && K >= 256 && fits32 && phased) {
       const int nbn = N / HBN_;
@@ -1267,7 +1353,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
         t.M = m_tail;
         a.M = m_main;
         hipLaunchKernelGGL(kern256p, dim3((nbm - r) * nbn), dim3(512), 131072, st, a);
-        hipLaunchKernelGGL(kern, dim3(((m_tail + GBM - 1) / GBM) * (N / GBN)), dim3(256), gsm, st, t);
+        hipLaunchKernelGGL(kern64, dim3(((m_tail + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, t);
       } else {
         hipLaunchKernelGGL(kern256p, dim3(nbm * nbn), dim3(512), 131072, st, a);
       }
@@ -1291,6 +1377,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     } else if (big) {
       const int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
       hipLaunchKernelGGL(kern256, dim3(nb), dim3(512), 131072, st, a);
+    } else if (Mm <= g64_maxm && fits32 && N % SBN == 0 && K % 64 == 0) {
+      hipLaunchKernelGGL(kern64, dim3(((Mm + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, a);
     } else {
       const int nb = ((Mm + GBM - 1) / GBM) * (N / GBN);
       hipLaunchKernelGGL(kern, dim3(nb), dim3(256), gsm, st, a);
@@ -1305,7 +1393,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     hipLaunchKernelGGL(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
                        g.image_size, g.patch, g.grid(), Kp);
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * E + 255) / 256), dim3(256), 0, st, ws.x, w.pos, B, S, E);
-    gemm(gemm_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0, false, false);
+    gemm(gemm_kernel<Op, EPI_PATCH>, gemm64_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0, false, false);
   }
   pf.end(0, st);
   const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
@@ -1317,25 +1405,25 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                        L.ln1_b, M, E, S);
     pf.end(1, st);
     pf.begin(2, st);
-    gemm(gemm_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
+    gemm(gemm_kernel<Op, EPI_QKV>, gemm64_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
     pf.end(2, st);
     pf.begin(3, st);
     hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H);
     pf.end(3, st);
     pf.begin(4, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
     pf.end(4, st);
     pf.begin(1, st);
     hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln2_s,
                        L.ln2_b, M, E, S);
     pf.end(1, st);
     pf.begin(5, st);
-    gemm(gemm_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0, false,
+    gemm(gemm_kernel<Op, EPI_GELU>, gemm64_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0, false,
          false);   // no peel: 12 tail tiles of 3084 gain nothing here, and the roofline kernel stays one launch
     pf.end(5, st);
     pf.begin(6, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
     pf.end(6, st);
   }
   pf.begin(1, st);
