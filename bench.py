@@ -27,6 +27,19 @@ import torch         # noqa: E402
 PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
+def fc1_main_rows(M, N, ncu):
+    """Rows the timed gemm256p_kernel launch of fc1 covers: csrc/encoder.hip peels the last M-tile rows onto gemm64_kernel
+    when that leaves the 256x256 grid a whole number of rounds of `ncu` workgroups (same rule as there)."""
+    if M < 1024 or M <= 2047 or N % 256:
+        return M
+    nbm, nbn = (M + 255) // 256, N // 256
+    rem = (nbm * nbn) % ncu
+    r = (rem + nbn - 1) // nbn
+    if rem > 0 and r * 8 <= nbm and ((nbm - r) * nbn) % ncu == 0 and M % 256 == 0:
+        return (nbm - r) * 256
+    return M
+
+
 def algorithmic_flops(g):
     """Per sample-step, counted as the reference executes them (SURVEY.md §8d / BASELINE.md §2)."""
     S, E, F, P, D, M, L = g.seq, g.enc_dim, g.enc_mlp, g.patches, g.dim, g.mlp, g.layers
@@ -270,7 +283,10 @@ def main():
     fl = algorithmic_flops(g)
     dom_ms = dom[0] / max(dom[1], 1)
     parts = 2 if (a.streams == 2 and B >= 64) else 1       # episodes per fc1 launch = B / parts
-    achieved = fl["fc1"] * (B / parts) / (dom_ms * 1e-3) / 1e12
+    rows = (B // parts) * (g.patches + 1)
+    main_rows = fc1_main_rows(rows, g.enc_mlp, torch.cuda.get_device_properties(dev).multi_processor_count)
+    fc1_flops = 2.0 * main_rows * g.enc_dim * g.enc_mlp    # of the timed launch (the 256x256 grid; tail rows run in gemm64_kernel)
+    achieved = fc1_flops / (dom_ms * 1e-3) / 1e12
     ms_per_step = elapsed / a.steps * 1e3
     out = {
         "metric": "actions_per_sec", "value": round(whole_job_rate(B, world, a.steps, elapsed), 2), "unit": "actions/s",
@@ -289,12 +305,12 @@ def main():
                                if ens is not None else "not in the step"},
         "latency_samples": len(lat),
         "p50_step_latency_ms": round(float(np.median(lat)), 4),
-        "roofline": {"bound": "mfma", "kernel": f"gemm256p_kernel<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",
+        "roofline": {"bound": "mfma", "kernel": ("gemm64_kernel" if rows <= 2047 else "gemm256p_kernel") + f"<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",
                      "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_unit": "bytes/launch (HBM-side, PMC: 2*FETCH_SIZE+WRITE_SIZE; algorithmic 510 MB)",
                      "launch_ms": round(dom_ms, 4), "launches_timed": dom[1],
-                     "flops_per_launch": fl["fc1"] * (B // parts)},
+                     "flops_per_launch": fc1_flops, "rows_per_launch": main_rows, "rows_total": rows},
         "step_tflops": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12, 2),
         "step_frac_of_peak": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
         "kernel_ms_per_step": breakdown,

@@ -22,6 +22,7 @@ for nm, (M_, N, K, epi) in shapes.items():
             continue
         ms = C.c_float()
         e = 1 if (6 <= variant <= 8 or 11 <= variant <= 23) else epi
+        if 'HVLA_DBG_EPI' in os.environ: e = int(os.environ['HVLA_DBG_EPI'])
         rc = lib.hvla_debug_gemm(m._ctx.h, M_, N, K, e, variant, 20, C.byref(ms))
         tf = 2.0 * M_ * N * K / (ms.value * 1e-3) / 1e12
         print(f"{nm:4s} M={M_} N={N} K={K} {names[variant]:20s} rc={rc} {ms.value*1e3:8.1f} us  {tf:7.1f} TF/s")
