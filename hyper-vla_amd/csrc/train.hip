@@ -282,22 +282,50 @@ __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the refills past kend (zeros) are still in flight
   const float* bias = g.bias && kc == 0 ? g.bias + b0 * g.sBias0 : nullptr;
+  // Straight-line epilogue per (full tile?, store mode): with per-element `m < M` branches and a run-time mode inside the
+  // loops the compiler drains the memory counter in every predicated block, i.e. one store round trip after the other.
+  auto store = [&](auto fullc, auto modec) {
+    constexpr bool FULL = decltype(fullc)::value;
+    constexpr int MODE = decltype(modec)::value;    // 0 store, 1 read-modify-write, 2 atomic add
 #pragma unroll
-  for (int b = 0; b < IN; ++b) {
-    const int n = n0 + wn * WN + b * 32 + col;
-    if (n >= g.N) continue;
-    const float bn = bias ? bias[n] : 0.f;
+    for (int b = 0; b < IN; ++b) {
+      const int n = n0 + wn * WN + b * 32 + col;
+      if (!FULL && n >= g.N) continue;
+      const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int a = 0; a < IM; ++a)
+      for (int a = 0; a < IM; ++a) {
+        float old[16];
+        if constexpr (MODE == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + a * 32 + crow(r, half);
-        if (m >= g.M) continue;
-        const float v = g.alpha * acc[a][b][r] + bn;
-        float* c = C + (long)m * g.ldc + n;
-        if (g.accumulate == 2 || g.ksplit > 1) unsafeAtomicAdd(c, v);
-        else *c = g.accumulate ? *c + v : v;
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WM + a * 32 + crow(r, half);
+            old[r] = (FULL || m < g.M) ? C[(long)m * g.ldc + n] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WM + a * 32 + crow(r, half);
+          if (!FULL && m >= g.M) continue;
+          const float v = g.alpha * acc[a][b][r] + bn;
+          float* c = C + (long)m * g.ldc + n;
+          if constexpr (MODE == 2) unsafeAtomicAdd(c, v);
+          else if constexpr (MODE == 1) *c = old[r] + v;
+          else *c = v;
+        }
       }
+    }
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  using M0 = std::integral_constant<int, 0>;
+  using M1 = std::integral_constant<int, 1>;
+  using M2 = std::integral_constant<int, 2>;
+  const bool full = m0 + BM <= g.M && n0 + BN <= g.N;
+  const int mode = (g.accumulate == 2 || g.ksplit > 1) ? 2 : (g.accumulate ? 1 : 0);
+  if (full) {
+    if (mode == 2) store(Yes{}, M2{}); else if (mode == 1) store(Yes{}, M1{}); else store(Yes{}, M0{});
+  } else {
+    if (mode == 2) store(No{}, M2{}); else if (mode == 1) store(No{}, M1{}); else store(No{}, M0{});
   }
 }
 
