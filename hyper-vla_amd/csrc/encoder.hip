@@ -1125,21 +1125,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthr = blockDim.x;
   const size_t rowstride = (size_t)3 * E;
   const T* base = qkv + (size_t)b * S * rowstride + head * 64;
-  // ---- stage K and V: 16 B per thread and chunk (zero rows for the padding keys)
-  for (int i = tid; i < SP * 8; i += nthr) {
-    const int key = i >> 3, ch = i & 7;
-    X8 kv, vv;
-    if (key < S) {
-      kv = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + E + ch * 8);
-      vv = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + 2 * E + ch * 8);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) kv[j] = (T)0.f, vv[j] = (T)0.f;
-    }
-    *reinterpret_cast<X8*>(Ks + key * AVLD + ((ch ^ (key & 7)) * 8)) = kv;
-    *reinterpret_cast<X8*>(Vs + key * AVLD + ((ch ^ (((key >> 1) & 1) << 2)) * 8)) = vv;
-  }
-  // ---- this wave's 32 queries as B fragments (natural d order): 4 k-steps of 16
+  // ---- this wave's 32 queries as B fragments (natural d order): 4 k-steps of 16 -- requested first, used last
   const int col = lane & 31, half = lane >> 5;
   const int q = wave * 32 + col;                           // always < S - 1
   X8 qf[4];
@@ -1149,6 +1135,31 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   X8 qx[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) qx[c] = *reinterpret_cast<const X8*>(base + (size_t)(S - 1) * rowstride + half * 32 + c * 8);
+  // ---- stage K and V: 16 B per thread and chunk (zero rows for the padding keys).  SP * 8 / nthr = 4 (NW + 1) / NW <= 8
+  // chunks per thread; ALL their loads are requested before the first LDS store (a rolled loop pays one HBM round trip
+  // per iteration: 5 in a row at S = 257, a third of the workgroup's life time).
+  constexpr int STG = 8;
+  X8 kreg[STG], vreg[STG];
+#pragma unroll
+  for (int it = 0; it < STG; ++it) {
+    if (it * nthr >= SP * 8) break;                        // uniform
+    const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kreg[it][j] = (T)0.f, vreg[it][j] = (T)0.f;
+    if (i < SP * 8 && key < S) {
+      kreg[it] = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + E + ch * 8);
+      vreg[it] = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + 2 * E + ch * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < STG; ++it) {
+    if (it * nthr >= SP * 8) break;
+    const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
+    if (i < SP * 8) {
+      *reinterpret_cast<X8*>(Ks + key * AVLD + ((ch ^ (key & 7)) * 8)) = kreg[it];
+      *reinterpret_cast<X8*>(Vs + key * AVLD + ((ch ^ (((key >> 1) & 1) << 2)) * 8)) = vreg[it];
+    }
+  }
   __syncthreads();
 
   // per-lane part of the transposed-read address: row (half * 4 + q), column 16 * dgrp + 4 p, and the 64-B
