@@ -46,17 +46,20 @@ __global__ void im2col_kernel(const uint8_t* __restrict__ img, typename Op::elem
     const size_t m = i / chunks;
     const int px = (int)(m % grid), py = (int)((m / grid) % grid);
     const size_t b = m / ((size_t)grid * grid);
+    // k = (dy * patch + dx) * 3 + c: a patch row is 3 * patch consecutive bytes of the image row, so one division finds
+    // (dy, byte in row) of the chunk's first element and the other seven follow by compare / subtract
     typename Op::x8 v;
+    const int rowb = 3 * patch;
+    int k0 = ch * 8;
+    k0 = k0 >= Kp1 ? k0 - Kp1 : k0;                  // Kp1 is a multiple of 8: a chunk never straddles the two halves
+    int dy = k0 / rowb, rb = k0 - dy * rowb;
+    const uint8_t* src = img + ((b * image + (size_t)(py * patch + dy)) * image + (size_t)px * patch) * 3;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      int k = ch * 8 + j;
-      k = k >= Kp1 ? k - Kp1 : k;
       float f = 0.f;
-      if (k < kreal) {
-        const int c = k % 3, dx = (k / 3) % patch, dy = k / (3 * patch);
-        f = (float)img[((b * image + (size_t)(py * patch + dy)) * image + (px * patch + dx)) * 3 + c] - 128.f;
-      }
+      if (k0 + j < kreal) f = (float)src[rb] - 128.f;
       v[j] = (typename Op::elem)f;
+      if (++rb == rowb) rb = 0, src += (size_t)image * 3;
     }
     *reinterpret_cast<typename Op::x8*>(out + m * Kp + ch * 8) = v;
   }
