@@ -1123,7 +1123,8 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   const int NW = (S - 1) / 32, KT = NW + 1, SP = KT * 32;
   T* Ks = reinterpret_cast<T*>(smem);                      // [SP][64]  keys, 16-B chunks XOR-swizzled by key & 7
   T* Vs = Ks + SP * AVLD;                                  // [SP][64]  values, row-major (read transposed)
-  float* part = reinterpret_cast<float*>(Vs + SP * AVLD);  // [KT][66]   partial (max, sum, O[64]) of the last query
+  T* qxs = Vs + SP * AVLD;                                 // [64]       the last query (parked here, not in registers)
+  float* part = reinterpret_cast<float*>(qxs + 64);        // [KT][66]   partial (max, sum, O[64]) of the last query
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthr = blockDim.x;
   const size_t rowstride = (size_t)3 * E;
@@ -1134,10 +1135,9 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   X8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const X8*>(base + (size_t)q * rowstride + ks * 16 + half * 8);
-  // the extra query (token S-1): lane holds d = 32 * half .. +32 of it
-  X8 qx[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) qx[c] = *reinterpret_cast<const X8*>(base + (size_t)(S - 1) * rowstride + half * 32 + c * 8);
+  // the extra query (token S-1) goes to LDS: 16 VGPRs less across the MFMA loops (the kernel runs at the 128-VGPR limit
+  // of 4 waves per SIMD)
+  if (tid < 8) *reinterpret_cast<X8*>(qxs + tid * 8) = *reinterpret_cast<const X8*>(base + (size_t)(S - 1) * rowstride + tid * 8);
   // ---- stage K and V: 16 B per thread and chunk (zero rows for the padding keys).  SP * 8 / nthr = 4 (NW + 1) / NW <= 8
   // chunks per thread; ALL their loads are requested before the first LDS store (a rolled loop pays one HBM round trip
   // per iteration: 5 in a row at S = 257, a third of the workgroup's life time).
@@ -1176,42 +1176,50 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   // per-tile rescale of O and the running-max bookkeeping.
   //   pass 1: row max (scores are in the log2 domain: q carries 1/sqrt(64) * log2 e from the QKV epilogue)
   //   pass 2: accumulator initialised to -max, so p = exp2(acc) with no subtract; invalid keys get -1e30
-  f32x16 init;                      // 0 for real keys, -1e30 for the padding keys of the last tile
-#pragma unroll
-  for (int r = 0; r < 16; ++r) init[r] = ((KT - 1) * 32 + crow(r, half) < S) ? 0.f : -1e30f;
   auto kfrag = [&](int kt, int ks) {
     return *reinterpret_cast<const X8*>(Ks + (kt * 32 + col) * AVLD + (((2 * ks + half) ^ kswz) * 8));
   };
+  // This kernel is VALU-issue-bound (it spent about 4 VALU cycles per MFMA cycle): the accumulator input of a score tile
+  // is the inline constant 0 and the padding mask only exists in the peeled last key tile, so the loops carry no
+  // per-element initialisation or select; -max goes into the exp2 argument.
+  auto qk = [&](int kt, f32x16 c) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) c = Op::mma32(kfrag(kt, ks), qf[ks], c);
+    return c;
+  };
+  auto zero16 = [] {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+  };
+  auto mask16 = [&] {                // 0 for real keys, -1e30 for the padding keys of the last tile
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = ((KT - 1) * 32 + crow(r, half) < S) ? 0.f : -1e30f;
+    return z;
+  };
   float mx = -1e30f;
-  for (int kt = 0; kt < KT; ++kt) {
-    f32x16 s;
-    if (kt == KT - 1) s = init;
-    else {
+  auto rowmax = [&](const f32x16& sc) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) s = Op::mma32(kfrag(kt, ks), qf[ks], s);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-  }
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+  };
+  for (int kt = 0; kt < KT - 1; ++kt) rowmax(qk(kt, zero16()));
+  rowmax(qk(KT - 1, mask16()));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float lsum = 0.f;                 // this half's partial denominator
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  f32x2v lsum2 = {0.f, 0.f};        // this half's partial denominator (two interleaved partial sums)
   f32x16 O[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) O[0][r] = 0.f, O[1][r] = 0.f;
-  for (int kt = 0; kt < KT; ++kt) {
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = (kt == KT - 1 ? init[r] : 0.f) - mx;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) s = Op::mma32(kfrag(kt, ks), qf[ks], s);
+  auto pv = [&](int kt, const f32x16& sc) {
     X8 pf[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[r]);
-      lsum += p;
-      pf[r >> 3][r & 7] = (T)p;
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2v p2 = {__builtin_amdgcn_exp2f(sc[r] - mx), __builtin_amdgcn_exp2f(sc[r + 1] - mx)};
+      lsum2 += p2;
+      pf[r >> 3][r & 7] = (T)p2[0];
+      pf[r >> 3][(r & 7) + 1] = (T)p2[1];
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -1222,7 +1230,10 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         O[mt] = Op::mma32(tr_read2<X8>(v0, v0 + 8 * AVLD), pf[sstep], O[mt]);
       }
     }
-  }
+  };
+  for (int kt = 0; kt < KT - 1; ++kt) pv(kt, qk(kt, zero16()));
+  pv(KT - 1, qk(KT - 1, mask16()));
+  const float lsum = lsum2[0] + lsum2[1];
   const float inv = 1.f / (lsum + __shfl_xor(lsum, 32, 64));
   {
     T* op = o + ((size_t)b * S + q) * E + head * 64;
@@ -1239,6 +1250,9 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   // ---- the last query, VALU: wave w scores key tile w (lane = key, the two halves split d), wave 0 also the
   // final key S-1; partial softmax + partial P.V (lane = d); combine across waves through LDS.
   {
+    X8 qx[4];                            // lane holds d = 32 * half .. +32 of the last query
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qx[c] = *reinterpret_cast<const X8*>(qxs + half * 32 + c * 8);
     auto score = [&](int key) {          // sum over this half's 32 d
       float a = 0.f;
       const T* kr = Ks + key * AVLD;
@@ -1405,7 +1419,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   }
   pf.end(0, st);
   const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
-  const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * 66 * sizeof(float);
+  const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * 66 * sizeof(float) + 64 * sizeof(T);
   for (int l = 0; l < g.enc_layers; ++l) {
     const EncLayerW& L = w.layer[l];
     pf.begin(1, st);
