@@ -1110,6 +1110,27 @@ __device__ __forceinline__ X8 tr_read2(const void* p0, const void* p1) {
   return __builtin_bit_cast(X8, v);
 }
 
+// 16-lane row reductions by DPP (quad swaps, then the half-row and row mirrors) and an SGPR broadcast of one lane
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  return fmaxf(v, dpp_mov<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  return v + dpp_mov<0x140>(v);
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 template <typename Op>
 __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, typename Op::elem* __restrict__ o,
                                  int S, int E, int H) {
@@ -1247,7 +1268,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         *reinterpret_cast<typename Op::x4*>(op + mt * 32 + g4 * 8 + half * 4) = v4;
       }
   }
-  // ---- the last query, VALU: wave w scores key tile w (lane = key, the two halves split d), wave 0 also the
+  // ---- the last query, VALU: wave w scores key tile w (lane = key, the two halves split d), the last wave also the
   // final key S-1; partial softmax + partial P.V (lane = d); combine across waves through LDS.
   {
     X8 qx[4];                            // lane holds d = 32 * half .. +32 of the last query
@@ -1264,28 +1285,32 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       }
       return a + __shfl_xor(a, 32, 64);
     };
-    const int nk = wave == 0 ? 2 : 1;    // wave 0: tile 0 and the single key of tile KT-1
-    for (int t = 0; t < nk; ++t) {
-      const int tile = t == 0 ? wave : KT - 1;
-      const int key = tile * 32 + col;
-      const bool valid = key < S;
-      const float sc = valid ? score(valid ? key : 0) : -1e30f;
-      float m = sc;
-#pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-      const float p = valid ? __builtin_amdgcn_exp2f(sc - m) : 0.f;
-      float l = p;
-#pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) l += __shfl_xor(l, off, 64);
+    // wave w: key tile w.  Reductions over the 32 keys by DPP inside the 16-lane rows + two readlanes (a ds_bpermute
+    // butterfly is five dependent LDS round trips), the P.V row by readlane broadcasts of p.
+    {
+      const int tile = wave;
+      const float sc = score(tile * 32 + col);
+      float m = row16_max(sc);
+      m = fmaxf(lane_bcast(m, 0), lane_bcast(m, 16));
+      const float p = __builtin_amdgcn_exp2f(sc - m);
+      float l = row16_sum(p);
+      l = lane_bcast(l, 0) + lane_bcast(l, 16);
       float od = 0.f;                    // lane = d
+#pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const float pi = __shfl(p, i, 64);
         const int k2 = tile * 32 + i;
-        od = fmaf(pi, (float)Vs[k2 * AVLD + (lane ^ (((k2 >> 1) & 1) << 5))], od);
+        od = fmaf(lane_bcast(p, i), (float)Vs[k2 * AVLD + (lane ^ (((k2 >> 1) & 1) << 5))], od);
       }
       float* pp = part + tile * 66;
       if (lane == 0) pp[0] = m, pp[1] = l;
       pp[2 + lane] = od;
+    }
+    if (wave == NW - 1) {                // the one real key of tile KT-1 (= S-1): p = 1, sum = 1, P.V = its V row
+      const int key = S - 1;
+      const float sc = score(key);
+      float* pp = part + (KT - 1) * 66;
+      if (lane == 0) pp[0] = sc, pp[1] = 1.f;
+      pp[2 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
     }
   }
   __syncthreads();
