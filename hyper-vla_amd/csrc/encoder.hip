@@ -1162,6 +1162,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   // ---- stage K and V: 16 B per thread and chunk (zero rows for the padding keys).  SP * 8 / nthr = 4 (NW + 1) / NW <= 8
   // chunks per thread; ALL their loads are requested before the first LDS store (a rolled loop pays one HBM round trip
   // per iteration: 5 in a row at S = 257, a third of the workgroup's life time).
+  // K first, then V: V is only needed in the second pass, so its loads stay in flight (in registers) under the first.
   constexpr int STG = 8;
   X8 kreg[STG], vreg[STG];
 #pragma unroll
@@ -1169,22 +1170,33 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     if (it * nthr >= SP * 8) break;                        // uniform
     const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) kreg[it][j] = (T)0.f, vreg[it][j] = (T)0.f;
-    if (i < SP * 8 && key < S) {
-      kreg[it] = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + E + ch * 8);
-      vreg[it] = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + 2 * E + ch * 8);
-    }
+    for (int j = 0; j < 8; ++j) kreg[it][j] = (T)0.f;
+    if (i < SP * 8 && key < S) kreg[it] = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + E + ch * 8);
   }
 #pragma unroll
   for (int it = 0; it < STG; ++it) {
     if (it * nthr >= SP * 8) break;
     const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
-    if (i < SP * 8) {
-      *reinterpret_cast<X8*>(Ks + key * AVLD + ((ch ^ (key & 7)) * 8)) = kreg[it];
-      *reinterpret_cast<X8*>(Vs + key * AVLD + ((ch ^ (((key >> 1) & 1) << 2)) * 8)) = vreg[it];
-    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vreg[it][j] = (T)0.f;
+    if (i < SP * 8 && key < S) vreg[it] = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + 2 * E + ch * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < STG; ++it) {
+    if (it * nthr >= SP * 8) break;
+    const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
+    if (i < SP * 8) *reinterpret_cast<X8*>(Ks + key * AVLD + ((ch ^ (key & 7)) * 8)) = kreg[it];
   }
   __syncthreads();
+  auto stage_v = [&] {
+#pragma unroll
+    for (int it = 0; it < STG; ++it) {
+      if (it * nthr >= SP * 8) break;
+      const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
+      if (i < SP * 8) *reinterpret_cast<X8*>(Vs + key * AVLD + ((ch ^ (((key >> 1) & 1) << 2)) * 8)) = vreg[it];
+    }
+    __syncthreads();
+  };
 
   // per-lane part of the transposed-read address: row (half * 4 + q), column 16 * dgrp + 4 p, and the 64-B
   // half swap of rows with bit 1 set (q >= 2)
@@ -1228,6 +1240,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   for (int kt = 0; kt < KT - 1; ++kt) rowmax(qk(kt, zero16()));
   rowmax(qk(KT - 1, mask16()));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  stage_v();
   typedef float f32x2v __attribute__((ext_vector_type(2)));
   f32x2v lsum2 = {0.f, 0.f};        // this half's partial denominator (two interleaved partial sums)
   f32x16 O[2];
