@@ -157,11 +157,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    # test hook only (tests/test_gpu_parity.py): all ranks on GPU 0 over gloo, so that the N > 1 control flow can be run on
+    # a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    share = os.environ.get("HVLA_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torch.distributed.run even at N = 1
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # RCCL; used only for barrier + max(time)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # RCCL; used only for barrier + max(time)
 
     from hypervla import synthetic as syn
     from hypervla.config import FULL, SMALL_E

@@ -544,3 +544,26 @@ def test_every_stage_is_run_to_run_deterministic(full):
         else:
             for name, x, y in zip(("ctx", "theta", "tokens", "actions", "logits"), cur, ref):
                 assert torch.equal(x, y), name
+
+
+@pytest.mark.gpu
+def test_bench_contract_with_two_ranks_on_one_gpu():
+    """bench.py's N > 1 control flow (barrier, max over ranks, rank 0 prints ONE line, whole-job value) on a one-GPU box:
+    two ranks share GPU 0 over gloo (test hook HVLA_BENCH_SHARE_GPU); the driver's real runs use RCCL, one rank per GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HVLA_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for extra in ([], ["--finetune"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+               "--batch", "8", "--no-cpu-baseline"] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+        assert d["config"]["global_batch"] == 16 if not extra else True
