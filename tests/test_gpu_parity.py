@@ -567,3 +567,22 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
         assert d["config"]["global_batch"] == 16 if not extra else True
+
+
+@pytest.mark.gpu
+def test_tokens_are_the_same_whichever_gemm_kernel_computes_them():
+    """Batch sizes on both sides of the kernel choices in csrc/encoder.hip -- gemm64_kernel up to 2047 rows (B <= 7), the
+    256x256 kernel above, with and without peeled tail rows -- give an image the same patch tokens, bit for bit."""
+    from hypervla.config import FULL
+    from hypervla.model import HyperVLA
+    from hypervla.synthetic import synthetic_images
+    m = HyperVLA.from_synthetic(FULL, max_batch=40)
+    im = synthetic_images(40, FULL)[:, 0]
+    ref = m.encode_images(im[:1]).cpu()                      # B = 1: 257 rows, gemm64_kernel
+    for B, pos in ((3, 0), (7, 0), (8, 0), (9, 0), (40, 0)):
+        tok = m.encode_images(im[:B]).cpu()
+        assert torch.equal(tok[pos], ref[0]), B
+    last = m.encode_images(im[39:40]).cpu()
+    assert torch.equal(m.encode_images(im).cpu()[39], last[0])
+    mixed = m.encode_images(np.ascontiguousarray(im[[5, 0, 39, 0]])).cpu()
+    assert torch.equal(mixed[1], ref[0]) and torch.equal(mixed[3], ref[0]) and torch.equal(mixed[2], last[0])
