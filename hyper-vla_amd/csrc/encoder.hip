@@ -509,10 +509,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     }
   };
   f32x4 acc[4][8];   // [n-tile][m-tile]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
   const int sw0 = ((fq) ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
   const int a_off = (wm * 128 + fr) * 128, w_off = 32768 + (wn * 64 + fr) * 128;
@@ -563,7 +559,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 // LDS image and swizzle are those of gemm256_kernel (128-byte rows, chunk ^= row & 7 on the source and on the read).
 // FL (diagnostics): 1 no stagger, 2 s_setprio(1) around the MFMA clusters (measured 10 % SLOWER here, off by default),
 // 4 no DMA in the loop, 8 no MFMA, 16 no fragment reads in the loop, 32 no epilogue
-template <typename Op, int EPI, bool PEEL = true, int FL = 0>
+template <typename Op, int EPI, bool PEEL = true, int FL = 0, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   using T = typename Op::elem;
   using X8 = typename Op::x8;
@@ -572,33 +568,52 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nbm = (g.M + HBM_ - 1) / HBM_, nbn = g.N / HBN_;
-  int bid = blockIdx.x;
-  {
-    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
+  const int ntiles = nbm * nbn;
   const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
-  constexpr int CH = 8;
-  const int per_chunk = CH * nbn;
-  const int chunk = bid / per_chunk, rc = bid % per_chunk;
-  const int rows = (nbm - chunk * CH) < CH ? (nbm - chunk * CH) : CH;
-  const int sc = rc / (rows * GN), r2 = rc % (rows * GN);
-  const int bm = chunk * CH + r2 / GN, bn = sc * GN + r2 % GN;
-  const int m0 = bm * HBM_, n0 = bn * HBN_;
+  // virtual block id v (= blockIdx.x, + k * gridDim.x in the persistent form: gridDim.x is a multiple of 8, so a workgroup
+  // stays in its XCD's id range) -> tile origin
+  auto tile_origin = [&](int v, int& m0, int& n0) {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = v % 8;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + v / 8;
+    constexpr int CH = 8;
+    const int per_chunk = CH * nbn;
+    const int chunk = bid / per_chunk, rc = bid % per_chunk;
+    const int rows = (nbm - chunk * CH) < CH ? (nbm - chunk * CH) : CH;
+    const int sc = rc / (rows * GN), r2 = rc % (rows * GN);
+    m0 = (chunk * CH + r2 / GN) * HBM_;
+    n0 = (sc * GN + r2 % GN) * HBN_;
+  };
+  int vb = blockIdx.x, m0, n0;
+  tile_origin(vb, m0, n0);
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
   // LDS-DMA pieces: instruction j of wave w fills rows [64 j + 8 w, +8) of A (or W); lane -> (row = lane >> 3, LDS chunk =
   // lane & 7), source chunk (lane & 7) ^ (row & 7).  Half-tile h = 0,1: A rows [128 h, +128) (j = 2h, 2h + 1); h = 2,3: W.
   const int srow = wave * 8 + (lane >> 3);
   const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
+  // PERSIST (every tile is full: the host peels the tail rows): one per-lane offset for A and one for W plus wave-uniform
+  // row bases, i.e. 2 VGPRs instead of 8 and SGPR-base addressing -- the tile loop has no registers to spare
   uint32_t aoff[4], woff[4];
+  const uint32_t lane_a = ((uint32_t)srow * (uint32_t)g.K + sch) * (uint32_t)sizeof(T);                 // bytes
+  const uint32_t lane_w = ((uint32_t)(wperm(srow)) * (uint32_t)g.K + sch) * (uint32_t)sizeof(T);        // wperm(64 j + srow) = 64 j + wperm(srow)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const T* abase = A;
+  const T* wbase = W;
+  auto offsets = [&](int tm0, int tn0) {
+    if constexpr (PERSIST) {
+      abase = A + (size_t)tm0 * g.K;
+      wbase = W + (size_t)tn0 * g.K;
+    } else {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + 64 * j + srow;
-    m = m < g.M ? m : g.M - 1;
-    aoff[j] = (uint32_t)m * (uint32_t)g.K + sch;
-    woff[j] = (uint32_t)(n0 + ((FL & 64) ? 64 * j + srow : wperm(64 * j + srow))) * (uint32_t)g.K + sch;   // column permutation of the epilogue
-  }
+      for (int j = 0; j < 4; ++j) {
+        int m = tm0 + 64 * j + srow;
+        m = m < g.M ? m : g.M - 1;
+        aoff[j] = (uint32_t)m * (uint32_t)g.K + sch;
+        woff[j] = (uint32_t)(tn0 + ((FL & 64) ? 64 * j + srow : wperm(64 * j + srow))) * (uint32_t)g.K + sch;   // column permutation of the epilogue
+      }
+    }
+  };
+  offsets(m0, n0);
   const int KT = g.K / 64;
   auto stage = [&](auto hc, int kt) {              // half-tile hc of K-tile kt (clamped) into buffer kt & 1
     constexpr int h = decltype(hc)::value;
@@ -608,16 +623,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int j = 2 * (h & 1) + u;
-      const T* src = (h < 2 ? A + aoff[j] : W + woff[j]) + kc * 64;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
+      if constexpr (PERSIST) {
+        // SGPR row base + 32-bit per-lane byte offset, issued by hand: the builtin always takes a 64-bit VGPR address
+        // (8 loop-invariant pairs that the register allocator spills, and every spill reload waits vmcnt(0))
+        const T* sb = (h < 2 ? abase : wbase) + ((size_t)j * 64 * g.K + kc * 64);
+        const uint32_t dst = lds0 + (uint32_t)(buf * 65536 + wave * 1024 + (h >> 1) * 32768 + j * 8192);
+        const uint32_t vo = h < 2 ? lane_a : lane_w;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(vo), "s"(sb), "s"(dst) : "m0");   // no "memory" clobber: it would make every issue wait for the
+                                                              // fragment reads in flight; barriers / counted waits order it
+      } else {
+        const T* src = (h < 2 ? A + aoff[j] : W + woff[j]) + kc * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
+      }
     }
   };
   f32x4 acc[4][8];   // [n-tile][m-tile]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
   const int sw0 = ((fq) ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
   const int a_off = (wm * 128 + fr) * 128, w_off = 32768 + (wn * 64 + fr) * 128;
@@ -671,8 +693,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  HVLA_BAR();
-  if (wm == 1 && !(FL & 1)) HVLA_BAR();             // waves 4-7 run half a phase behind
   // one K-tile = four phases.  S1: tile kt+1 exists (stage its W halves in phases 1, 2); S2: tile kt+2 exists (stage its A
   // halves in phases 3, 4).  The last two K-tiles are peeled so that nothing is staged past the end and the phase-4 wait
   // stays an immediate: vmcnt(4) with both A halves of tile kt+2 in flight, vmcnt(0) without.
@@ -711,32 +731,63 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
-  if constexpr (PEEL) {
-    int kt = 0;
-    for (; kt + 2 < KT; ++kt) ktile(kt, Yes{}, Yes{});
-    if (kt + 1 < KT) { ktile(kt, Yes{}, No{}); ++kt; }
-    ktile(kt, No{}, No{});
-  } else {      // diagnostics: stage past the end (clamped re-loads of the last tile), one loop body
-    for (int kt = 0; kt < KT; ++kt) ktile(kt, Yes{}, Yes{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  if (wm == 0 && !(FL & 1)) HVLA_BAR();             // same number of barriers in both wave rows
-#undef HVLA_BAR
-  if constexpr (FL & 32) {                          // diagnostics: no epilogue (one lane keeps the accumulators alive)
-    float s = 0.f;
+  // PERSIST: gridDim.x workgroups walk the tiles v, v + gridDim.x, ...; the prologue DMA of the next tile (K-tile 0 and the
+  // A halves of K-tile 1) is issued BEFORE this tile's epilogue, so its latency and the workgroup launch disappear under
+  // the epilogue's VALU work and stores.  The wait for it counts the epilogue's memory operations, which were issued later
+  // (vmcnt retires in order): at least 32 stores per wave, so vmcnt(36) leaves those and the two A halves in flight.
+  while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (s == 12345.678f) reinterpret_cast<float*>(g.out)[0] = s;
-    return;
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    HVLA_BAR();
+    if (wm == 1 && !(FL & 1)) HVLA_BAR();             // waves 4-7 run half a phase behind
+    if constexpr (PEEL) {
+      int kt = 0;
+      for (; kt + 2 < KT; ++kt) ktile(kt, Yes{}, Yes{});
+      if (kt + 1 < KT) { ktile(kt, Yes{}, No{}); ++kt; }
+      ktile(kt, No{}, No{});
+    } else {      // diagnostics: stage past the end (clamped re-loads of the last tile), one loop body
+      for (int kt = 0; kt < KT; ++kt) ktile(kt, Yes{}, Yes{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (wm == 0 && !(FL & 1)) HVLA_BAR();             // same number of barriers in both wave rows
+    const int cm0 = m0, cn0 = n0;
+    bool more = false;
+    if constexpr (PERSIST) {
+      vb += gridDim.x;
+      more = vb < ntiles;
+      if (more) {
+        tile_origin(vb, m0, n0);
+        offsets(m0, n0);
+        stage(H0{}, 0); stage(H1{}, 0); stage(H2{}, 0); stage(H3{}, 0);
+        stage(H0{}, 1); stage(H1{}, 1);
+      }
+    }
+    if constexpr (FL & 32) {                          // diagnostics: no epilogue (one lane keeps the accumulators alive)
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (s == 12345.678f) reinterpret_cast<float*>(g.out)[0] = s;
+    } else if constexpr (FL & 64) {
+      gemm_epilogue<Op, EPI, 4, 8>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq);
+    } else if constexpr (FL & 128) {                  // diagnostics: every CU stores into the first tile rows (stays in L2)
+      gemm_epilogue_rows<Op, EPI, 8>(acc, g, wm * 128, (blockIdx.x % (g.N / HBN_)) * HBN_ + wn * 64, fr, fq);
+    } else {
+      gemm_epilogue_rows<Op, EPI, 8>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq);
+    }
+    if (!more) break;
+    if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) {
+      if (cm0 + HBM_ <= g.M) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // an edge tile issues fewer stores
+    } else {
+      if (cm0 + HBM_ <= g.M) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");   // 64+ loads and stores behind the DMA
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
-  if constexpr (FL & 64) { gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq); return; }
-  if constexpr (FL & 128) {                         // diagnostics: every CU stores into the first tile rows (stays in L2)
-    gemm_epilogue_rows<Op, EPI, 8>(acc, g, wm * 128, (blockIdx.x % (g.N / HBN_)) * HBN_ + wn * 64, fr, fq);
-    return;
-  }
-  gemm_epilogue_rows<Op, EPI, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+#undef HVLA_BAR
 }
 
 // In-place residual epilogue of the ring kernel with the x tile PREFETCHED by LDS-DMA.  Loading x through
@@ -1366,6 +1417,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm256r_kernel<Op, EPI_RES>))
     SETA((gemm256p_kernel<Op, EPI_PATCH>)) SETA((gemm256p_kernel<Op, EPI_QKV>)) SETA((gemm256p_kernel<Op, EPI_GELU>))
     SETA((gemm256p_kernel<Op, EPI_RES>))
+    SETA((gemm256p_kernel<Op, EPI_PATCH, true, 0, true>)) SETA((gemm256p_kernel<Op, EPI_QKV, true, 0, true>))
+    SETA((gemm256p_kernel<Op, EPI_GELU, true, 0, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true, 0, true>))
     SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
     SETA((gemm64_kernel<Op, EPI_RES>))
 #undef SETA
@@ -1374,6 +1427,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" | "phase" | "ring" select a kernel
   static const bool phased = !(gsel && !strcmp(gsel, "ring"));
   static const bool nopeel = getenv("HVLA_NO_PEEL") != nullptr;
+  static const bool nopersist = getenv("HVLA_NO_PERSIST") != nullptr;
   static const int g64_maxm = getenv("HVLA_G64_MAXM") ? atoi(getenv("HVLA_G64_MAXM")) : 2047;   // rows up to which the 64x64 kernel is used
   // split-K of the tail-round tiles of the residual GEMMs is opt-in: it buys < 1 % of the step, and its f32 atomic adds make
   // the one episode that owns those rows run-to-run different by up to 2e-3 in its tokens (tools/tail_probe.py)
@@ -1386,7 +1440,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
   }
   bool fc1_main_closed = false;   // profiler mode 1: the fc1 bracket covers the 256x256 launch only (see gemm)
-  auto gemm = [&](auto kern, auto kern64, auto kern256, auto kern256r, auto kern256p, const void* A, const void* Wt, int Mm, int N, int K,
+  auto gemm = [&](auto kern, auto kern64, auto kern256, auto kern256r, auto kern256p, auto kern256pp, const void* A, const void* Wt, int Mm, int N, int K,
                   const float* bias, const float* aux, void* out, int qcols, bool is_res = false, bool peel = true,
                   int main_cat = -1) {
     GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
@@ -1411,9 +1465,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                        : static_cast<void*>(reinterpret_cast<T*>(out) + (size_t)m_main * N);
         t.M = m_tail;
         a.M = m_main;
-        hipLaunchKernelGGL(kern256p, dim3((nbm - r) * nbn), dim3(512), 131072, st, a);
+        // whole rounds of full tiles: one persistent workgroup per CU walks them, with the next tile's first DMA in flight
+        // under the current tile's epilogue
+        if (!nopersist && K >= 128) hipLaunchKernelGGL(kern256pp, dim3(ncu), dim3(512), 131072, st, a);
+        else hipLaunchKernelGGL(kern256p, dim3((nbm - r) * nbn), dim3(512), 131072, st, a);
         if (main_cat >= 0 && pf.mode == 1) { pf.end(main_cat, st); fc1_main_closed = true; }
         hipLaunchKernelGGL(kern64, dim3(((m_tail + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, t);
+      } else if (!nopersist && K >= 128 && Mm % HBM_ == 0 && (nbm * nbn) % ncu == 0) {
+        hipLaunchKernelGGL(kern256pp, dim3(ncu), dim3(512), 131072, st, a);
       } else {
         hipLaunchKernelGGL(kern256p, dim3(nbm * nbn), dim3(512), 131072, st, a);
       }
@@ -1453,7 +1512,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     hipLaunchKernelGGL(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
                        g.image_size, g.patch, g.grid(), Kp);
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * E + 255) / 256), dim3(256), 0, st, ws.x, w.pos, B, S, E);
-    gemm(gemm_kernel<Op, EPI_PATCH>, gemm64_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0, false, false);
+    gemm(gemm_kernel<Op, EPI_PATCH>, gemm64_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH, true, 0, true>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0, false, false);
   }
   pf.end(0, st);
   const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
@@ -1465,14 +1524,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                        L.ln1_b, M, E, S);
     pf.end(1, st);
     pf.begin(2, st);
-    gemm(gemm_kernel<Op, EPI_QKV>, gemm64_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
+    gemm(gemm_kernel<Op, EPI_QKV>, gemm64_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV, true, 0, true>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
     pf.end(2, st);
     pf.begin(3, st);
     hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H);
     pf.end(3, st);
     pf.begin(4, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES, true, 0, true>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
     pf.end(4, st);
     pf.begin(1, st);
     hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln2_s,
@@ -1480,11 +1539,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     pf.end(1, st);
     fc1_main_closed = false;
     pf.begin(5, st);   // in "dominant kernel only" mode the bracket is closed right behind the main launch (inside gemm)
-    gemm(gemm_kernel<Op, EPI_GELU>, gemm64_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0, false,
+    gemm(gemm_kernel<Op, EPI_GELU>, gemm64_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU, true, 0, true>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0, false,
          true, 5);
     if (!(pf.mode == 1 && fc1_main_closed)) pf.end(5, st);
     pf.begin(6, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES, true, 0, true>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
     pf.end(6, st);
   }
   pf.begin(1, st);
@@ -1546,6 +1605,11 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
       if (variant == 19) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 24>), dim3(nb256), dim3(512), 131072, st, a);
       if (variant == 20) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 21>), dim3(nb256), dim3(512), 131072, st, a);
       if (variant == 21) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 32>), dim3(nb256), dim3(512), 131072, st, a);
+    } else if (variant == 27) {
+      const int grid = nb256 < 256 ? nb256 : 256;
+#define L256PP(E) hipLaunchKernelGGL((gemm256p_kernel<Op, E, true, 0, true>), dim3(grid), dim3(512), 131072, st, a)
+      if (epi == EPI_QKV) L256PP(EPI_QKV); else if (epi == EPI_GELU) L256PP(EPI_GELU); else L256PP(EPI_RES);
+#undef L256PP
     } else if (variant >= 22 && variant <= 25) {
       if (variant == 22) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 64>), dim3(nb256), dim3(512), 131072, st, a);
       if (variant == 23) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_QKV, true, 128>), dim3(nb256), dim3(512), 131072, st, a);
@@ -1569,6 +1633,9 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_GELU, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_RES, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<Op, EPI_QKV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
