@@ -26,6 +26,7 @@ python bench.py --finetune --batch 32 --steps 10 --warmup 3 > $P/r1_finetune_b32
 python bench.py --finetune --batch 256 --steps 10 --warmup 3 > $P/r1_finetune_b256_frozen_encoder.json 2>/dev/null
 python tools/blas_ref_bench.py > $P/r1_vendor_gemm_reference.txt 2>/dev/null
 HVLA_VARIANTS=5,9 python tools/gemm_bench.py 256 > $P/r1_gemm_isolated.txt 2>/dev/null
+HVLA_DBG_MSHRINK=256 HVLA_VARIANTS=9,27 python tools/gemm_bench.py 256 >> $P/r1_gemm_isolated.txt 2>/dev/null   # whole rounds: one launch per tile vs persistent
 python tools/bgemm_bench.py > $P/r1_train_gemm_isolated.txt 2>/dev/null
 python tools/determinism_probe.py > $P/r1_determinism.txt 2>/dev/null
 ls $P
