@@ -185,12 +185,12 @@ __device__ __forceinline__ int wperm(int rho) { return (rho & ~63) + 4 * (rho & 
 
 template <typename Op, int EPI, int MT, bool FULL>
 __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
-                                                        int fr, int fq) {
+                                                        int fr, int fq, const f32x4* pre_b4, const f32x4* pre_l4) {
   using T = typename Op::elem;
   const int n = n_base + 4 * fr;
-  const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+  const f32x4 b4 = pre_b4 ? *pre_b4 : *reinterpret_cast<const f32x4*>(g.bias + n);
   f32x4 l4 = f32x4{1.f, 1.f, 1.f, 1.f};
-  if constexpr (EPI == EPI_RES) l4 = *reinterpret_cast<const f32x4*>(g.aux + n);
+  if constexpr (EPI == EPI_RES) l4 = pre_l4 ? *pre_l4 : *reinterpret_cast<const f32x4*>(g.aux + n);
   const float q = EPI == EPI_PATCH ? g.qscale : ((EPI == EPI_QKV && n_base < g.qcols) ? g.qscale : 1.f);
   // FULL (every row of the wave tile exists): straight-line code, 32-bit element offsets from the uniform base.  With the
   // per-row `m < M` branches the compiler has to put an s_waitcnt vmcnt(0) into every predicated block (for the bias load),
@@ -256,9 +256,10 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
 
 template <typename Op, int EPI, int MT>
 __device__ __forceinline__ void gemm_epilogue_rows(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
-                                                   int fr, int fq) {
-  if (m_base + 16 * MT <= g.M) gemm_epilogue_rows_impl<Op, EPI, MT, true>(acc, g, m_base, n_base, fr, fq);
-  else gemm_epilogue_rows_impl<Op, EPI, MT, false>(acc, g, m_base, n_base, fr, fq);
+                                                   int fr, int fq, const f32x4* pre_b4 = nullptr,
+                                                   const f32x4* pre_l4 = nullptr) {
+  if (m_base + 16 * MT <= g.M) gemm_epilogue_rows_impl<Op, EPI, MT, true>(acc, g, m_base, n_base, fr, fq, pre_b4, pre_l4);
+  else gemm_epilogue_rows_impl<Op, EPI, MT, false>(acc, g, m_base, n_base, fr, fq, pre_b4, pre_l4);
 }
 
 // split-K tail tiles of a RES GEMM: x += (acc + [part 0] bias) * layerscale with f32 atomics
@@ -754,7 +755,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     if (wm == 0 && !(FL & 1)) HVLA_BAR();             // same number of barriers in both wave rows
     const int cm0 = m0, cn0 = n0;
     bool more = false;
+    f32x4 pb4, pl4;
     if constexpr (PERSIST) {
+      // bias / LayerScale of this tile are fetched and WAITED FOR before the next tile's DMA goes out: the compiler does not
+      // see the hand-issued DMA, so a wait it places after that point is a vmcnt(0) that would drain the prefetch
+      pb4 = *reinterpret_cast<const f32x4*>(g.bias + cn0 + wn * 64 + 4 * fr);
+      pl4 = pb4;
+      if constexpr (EPI == EPI_RES) pl4 = *reinterpret_cast<const f32x4*>(g.aux + cn0 + wn * 64 + 4 * fr);
+      asm volatile("" : "+v"(pb4), "+v"(pl4));
       vb += gridDim.x;
       more = vb < ntiles;
       if (more) {
@@ -776,7 +784,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     } else if constexpr (FL & 128) {                  // diagnostics: every CU stores into the first tile rows (stays in L2)
       gemm_epilogue_rows<Op, EPI, 8>(acc, g, wm * 128, (blockIdx.x % (g.N / HBN_)) * HBN_ + wn * 64, fr, fq);
     } else {
-      gemm_epilogue_rows<Op, EPI, 8>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq);
+      if constexpr (PERSIST) gemm_epilogue_rows<Op, EPI, 8>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
+      else gemm_epilogue_rows<Op, EPI, 8>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq);
     }
     if (!more) break;
     if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) {
