@@ -85,7 +85,7 @@ struct hvla_ctx {
   }
   // observation preprocessing (hvla_preprocess): span tables of the last (H, W) and scratch
   int rs_H = 0, rs_W = 0, rs_row_span = 0, rs_col_span = 0;
-  DevBuf rs_tab, rs_rows, rs_img;
+  DevBuf rs_tab, rs_rows, rs_img, rs_pad;
   // optional frozen T5 instruction encoder (hvla_t5_load)
   bool t5_loaded = false;
   T5Dims t5d{};
@@ -627,19 +627,22 @@ int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_tr
   return HVLA_OK;
 }
 
-int hvla_preprocess(hvla_ctx* ctx, const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t crop, uint8_t* images,
+int hvla_preprocess(hvla_ctx* ctx, const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t flags, uint8_t* images,
                     void* stream) {
   if (!ctx) return HVLA_E_STATE;
   if (B < 1 || H < 2 || W < 2 || H > 8192 || W > 8192) FAIL(ctx, HVLA_E_SHAPE, "frames [%d, %d, %d, 3]", B, H, W);
   if (!frames || !images) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  if (flags & ~3) FAIL(ctx, HVLA_E_SHAPE, "flags %d (1 = crop, 2 = padded resize)", flags);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int S = ctx->g.image_size;
+  const bool crop = flags & HVLA_PREPROCESS_CROP, pad = flags & HVLA_PREPROCESS_PAD;
+  const int LH = pad ? 256 : H, LW = pad ? 320 : W;           // what the lanczos3 stage sees (hypervla_interface.py:90-95)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (H != ctx->rs_H || W != ctx->rs_W) {                      // new source shape: rebuild the span tables
+  if (LH != ctx->rs_H || LW != ctx->rs_W) {                    // new source shape: rebuild the span tables
     std::vector<int> rs, rc, cs, cc;
     std::vector<float> rw, cw;
-    build_resize_spans(H, S, rs, rc, rw, ctx->rs_row_span);
-    build_resize_spans(W, S, cs, cc, cw, ctx->rs_col_span);
+    build_resize_spans(LH, S, rs, rc, rw, ctx->rs_row_span);
+    build_resize_spans(LW, S, cs, cc, cw, ctx->rs_col_span);
     std::vector<float> host;                                    // [row start | row count | col start | col count] as ints, then weights
     host.resize((size_t)4 * S + rw.size() + cw.size());
     memcpy(host.data(), rs.data(), (size_t)S * 4); memcpy(host.data() + S, rc.data(), (size_t)S * 4);
@@ -648,19 +651,21 @@ int hvla_preprocess(hvla_ctx* ctx, const uint8_t* frames, int32_t B, int32_t H, 
     HIPCHK(ctx, hipStreamSynchronize(st));                      // a previous call may still read the old tables
     HIPCHK(ctx, ctx->rs_tab.alloc(host.size() * 4));
     HIPCHK(ctx, hipMemcpy(ctx->rs_tab.p, host.data(), host.size() * 4, hipMemcpyHostToDevice));
-    ctx->rs_H = H; ctx->rs_W = W;
+    ctx->rs_H = LH; ctx->rs_W = LW;
   }
-  const size_t need_rows = (size_t)B * S * W * 3 * 4, need_img = (size_t)B * S * S * 3 * 4;
-  if (ctx->rs_rows.bytes < need_rows || ctx->rs_img.bytes < need_img) {
+  const size_t need_rows = (size_t)B * S * LW * 3 * 4, need_img = (size_t)B * S * S * 3 * 4;
+  const size_t need_pad = pad ? (size_t)B * LH * LW * 3 * 4 : 0;
+  if (ctx->rs_rows.bytes < need_rows || ctx->rs_img.bytes < need_img || ctx->rs_pad.bytes < need_pad) {
     HIPCHK(ctx, hipStreamSynchronize(st));
     if (ctx->rs_rows.bytes < need_rows) HIPCHK(ctx, ctx->rs_rows.alloc(need_rows));
     if (ctx->rs_img.bytes < need_img) HIPCHK(ctx, ctx->rs_img.alloc(need_img));
+    if (ctx->rs_pad.bytes < need_pad) HIPCHK(ctx, ctx->rs_pad.alloc(need_pad));
   }
   const int* ti = ctx->rs_tab.as<int>();
   const float* tw = ctx->rs_tab.as<float>() + 4 * S;
   HIPCHK(ctx, launch_resize(frames, images, ctx->rs_rows.as<float>(), ctx->rs_img.as<float>(), ti, ti + S, tw,
-                            ctx->rs_row_span, ti + 2 * S, ti + 3 * S, tw + (size_t)S * ctx->rs_row_span, ctx->rs_col_span, B, H, W,
-                            S, crop != 0, st));
+                            ctx->rs_row_span, ti + 2 * S, ti + 3 * S, tw + (size_t)S * ctx->rs_row_span, ctx->rs_col_span, B, LH,
+                            LW, S, crop, st, pad ? ctx->rs_pad.as<float>() : nullptr, H, W));
   return HVLA_OK;
 }
 

@@ -631,8 +631,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         const uint32_t dst = lds0 + (uint32_t)(buf * 65536 + wave * 1024 + (h >> 1) * 32768 + j * 8192);
         const uint32_t vo = h < 2 ? lane_a : lane_w;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     :: "v"(vo), "s"(sb), "s"(dst) : "m0");   // no "memory" clobber: it would make every issue wait for the
-                                                              // fragment reads in flight; barriers / counted waits order it
+                     :: "v"(vo), "s"(sb), "s"(dst) );        // no "memory" clobber: it would make every issue wait for the fragment reads in
+                                                       // flight (barriers / counted waits order it); M0 is reserved by the
+                                                       // compiler, which has no use of its own for it in this instantiation
       } else {
         const T* src = (h < 2 ? A + aoff[j] : W + woff[j]) + kc * 64;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,

@@ -92,7 +92,8 @@ void build_resize_spans(int in_size, int out_size, std::vector<int>& start, std:
                         int& maxspan);
 hipError_t launch_resize(const uint8_t* src, uint8_t* dst, float* tmp_rows, float* tmp_img, const int* row_start,
                          const int* row_count, const float* row_w, int row_span, const int* col_start, const int* col_count,
-                         const float* col_w, int col_span, int B, int H, int W, int S, int crop, hipStream_t st);
+                         const float* col_w, int col_span, int B, int H, int W, int S, int crop, hipStream_t st,
+                         float* padded = nullptr, int src_h = 0, int src_w = 0);   // padded: f32 [B][H][W][3] scratch of resize_with_pad
 
 // ---------------------------------------------------------------- generated policy
 struct PolicyParams {

@@ -51,14 +51,43 @@ void build_resize_spans(int in_size, int out_size, std::vector<int>& start, std:
   }
 }
 
-// rows: tmp[b][y][x][c] = sum_k w[y][k] * src[b][start[y] + k][x][c]       (src u8 [B][H][W][3], tmp f32 [B][S][W][3])
-__global__ void resize_rows_kernel(const uint8_t* __restrict__ src, float* __restrict__ tmp, const int* __restrict__ start,
+// optional first stage, tf.image.resize_with_pad(image, PH, PW) (hypervla_interface.py:90-95): legacy bilinear resize with
+// half-pixel centres to (rh, rw) = floor(size / max(W / PW, H / PH)), zero padding around it; f32 [B][PH][PW][3]
+__global__ void pad_bilinear_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int PH,
+                                    int PW, int rh, int rw, int ph, int pw) {
+  const long n = (long)B * PH * PW * 3;
+  const float ys = __fdiv_rn((float)H, (float)rh), xs = __fdiv_rn((float)W, (float)rw);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 3), x = (int)((i / 3) % PW) - pw, y = (int)((i / (3L * PW)) % PH) - ph;
+    const long b = i / (3L * PW * PH);
+    float v = 0.f;
+    if (x >= 0 && x < rw && y >= 0 && y < rh) {
+      const float in_y = __fadd_rn(__fmul_rn(__fadd_rn((float)y, 0.5f), ys), -0.5f);
+      const float in_x = __fadd_rn(__fmul_rn(__fadd_rn((float)x, 0.5f), xs), -0.5f);
+      const float fy = floorf(in_y), fx = floorf(in_x);
+      int y0 = (int)fy, y1 = (int)ceilf(in_y), x0 = (int)fx, x1 = (int)ceilf(in_x);
+      y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+      y1 = y1 > H - 1 ? H - 1 : y1; x1 = x1 > W - 1 ? W - 1 : x1;
+      const float ly = in_y - fy, lx = in_x - fx;
+      const uint8_t* base = src + b * H * W * 3 + c;
+      const float tl = (float)base[((long)y0 * W + x0) * 3], tr = (float)base[((long)y0 * W + x1) * 3];
+      const float bl = (float)base[((long)y1 * W + x0) * 3], br = (float)base[((long)y1 * W + x1) * 3];
+      const float top = __fadd_rn(tl, __fmul_rn(tr - tl, lx)), bot = __fadd_rn(bl, __fmul_rn(br - bl, lx));
+      v = __fadd_rn(top, __fmul_rn(bot - top, ly));
+    }
+    dst[i] = v;
+  }
+}
+
+// rows: tmp[b][y][x][c] = sum_k w[y][k] * src[b][start[y] + k][x][c]       (src u8 or f32 [B][H][W][3], tmp f32 [B][S][W][3])
+template <typename SRC>
+__global__ void resize_rows_kernel(const SRC* __restrict__ src, float* __restrict__ tmp, const int* __restrict__ start,
                                    const int* __restrict__ count, const float* __restrict__ w, int maxspan, int B, int H,
                                    int W, int S) {
   const long n = (long)B * S * W * 3;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int xc = (int)(i % (W * 3)), y = (int)((i / (W * 3)) % S), b = (int)(i / ((long)W * 3 * S));
-    const uint8_t* p = src + ((long)b * H + start[y]) * W * 3 + xc;
+    const SRC* p = src + ((long)b * H + start[y]) * W * 3 + xc;
     const float* wy = w + (long)y * maxspan;
     float acc = 0.f;
     for (int k = 0; k < count[y]; ++k) acc = __fadd_rn(acc, __fmul_rn(wy[k], (float)p[(long)k * W * 3]));
@@ -114,11 +143,32 @@ __global__ void resize_finish_kernel(const float* __restrict__ img, uint8_t* __r
 
 static inline dim3 g1(long n) { long b = (n + 255) / 256; return dim3((unsigned)(b > 16384 ? 16384 : b)); }
 
+void resize_with_pad_dims(int H, int W, int PH, int PW, int& rh, int& rw, int& ph, int& pw) {
+  const float r1 = (float)W / (float)PW, r2 = (float)H / (float)PH, ratio = r1 > r2 ? r1 : r2;
+  const float rhf = (float)H / ratio, rwf = (float)W / ratio;
+  rh = (int)floorf(rhf);
+  rw = (int)floorf(rwf);
+  ph = (int)floorf(((float)PH - rhf) / 2.f);
+  pw = (int)floorf(((float)PW - rwf) / 2.f);
+  ph = ph < 0 ? 0 : ph;
+  pw = pw < 0 ? 0 : pw;
+}
+
 hipError_t launch_resize(const uint8_t* src, uint8_t* dst, float* tmp_rows, float* tmp_img, const int* row_start,
                          const int* row_count, const float* row_w, int row_span, const int* col_start, const int* col_count,
-                         const float* col_w, int col_span, int B, int H, int W, int S, int crop, hipStream_t st) {
-  hipLaunchKernelGGL(resize_rows_kernel, g1((long)B * S * W * 3), dim3(256), 0, st, src, tmp_rows, row_start, row_count, row_w,
-                     row_span, B, H, W, S);
+                         const float* col_w, int col_span, int B, int H, int W, int S, int crop, hipStream_t st,
+                         float* padded, int src_h, int src_w) {
+  if (padded) {                                      // (H, W) = padded size, (src_h, src_w) = camera frame
+    int rh, rw, ph, pw;
+    resize_with_pad_dims(src_h, src_w, H, W, rh, rw, ph, pw);
+    hipLaunchKernelGGL(pad_bilinear_kernel, g1((long)B * H * W * 3), dim3(256), 0, st, src, padded, B, src_h, src_w, H, W, rh,
+                       rw, ph, pw);
+    hipLaunchKernelGGL(resize_rows_kernel<float>, g1((long)B * S * W * 3), dim3(256), 0, st, (const float*)padded, tmp_rows,
+                       row_start, row_count, row_w, row_span, B, H, W, S);
+  } else {
+    hipLaunchKernelGGL(resize_rows_kernel<uint8_t>, g1((long)B * S * W * 3), dim3(256), 0, st, src, tmp_rows, row_start, row_count,
+                       row_w, row_span, B, H, W, S);
+  }
   hipLaunchKernelGGL(resize_cols_kernel, g1((long)B * S * S * 3), dim3(256), 0, st, tmp_rows, tmp_img, col_start, col_count,
                      col_w, col_span, B, W, S);
   const double scale = sqrt(0.9), off = (1.0 - scale) / 2.0;         // python floats in the reference, cast with the box

@@ -189,8 +189,9 @@ class Context:
                              max_tokens, max_batch)
         self._check(self.lib.hvla_t5_load(self.h, C.byref(cfg), descs, len(params)), "hvla_t5_load")
 
-    def preprocess(self, src_ptr, B, H, W, crop, dst_ptr, stream=0):
-        self._check(self.lib.hvla_preprocess(self.h, src_ptr, B, H, W, int(crop), dst_ptr, C.c_void_p(stream)), "hvla_preprocess")
+    def preprocess(self, src_ptr, B, H, W, crop, dst_ptr, stream=0, padded_resize=False):
+        flags = (1 if crop else 0) | (2 if padded_resize else 0)          # HVLA_PREPROCESS_CROP | HVLA_PREPROCESS_PAD
+        self._check(self.lib.hvla_preprocess(self.h, src_ptr, B, H, W, flags, dst_ptr, C.c_void_p(stream)), "hvla_preprocess")
 
     def t5_encode(self, ids_ptr, mask_ptr, out_ptr, B, T, stream=0):
         self._check(self.lib.hvla_t5_encode(self.h, ids_ptr, mask_ptr, out_ptr, B, T, C.c_void_p(stream)), "hvla_t5_encode")

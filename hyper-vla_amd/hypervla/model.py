@@ -170,9 +170,10 @@ class HyperVLA:
         return torch.as_tensor(np.ascontiguousarray(np.asarray(a))).to(device=self.device, dtype=dtype).contiguous()
 
     # ------------------------------------------------------------------ observation preprocessing
-    def preprocess_images(self, frames, crop: bool = False):
-        """`InferenceWrapper._resize_image` (data/utils/hypervla_interface.py:89-121, no padded_resize) on the device:
-        uint8 camera frames [B, H, W, 3] (or [H, W, 3]) -> uint8 [B, image_size, image_size, 3] CUDA tensor."""
+    def preprocess_images(self, frames, crop: bool = False, padded_resize: bool = False):
+        """`InferenceWrapper._resize_image` (data/utils/hypervla_interface.py:89-121) on the device: uint8 camera frames
+        [B, H, W, 3] (or [H, W, 3]) -> uint8 [B, image_size, image_size, 3] CUDA tensor.  `padded_resize` first fits the
+        frame into 256 x 320 with zero padding (`tf.image.resize_with_pad`, the "rtx" augmentation style)."""
         torch = _torch()
         f = self._dev(frames, torch.uint8)
         if f.dim() == 3:
@@ -182,7 +183,7 @@ class HyperVLA:
         B, H, W, _ = f.shape
         S = self.geometry.image_size
         out = torch.empty(B, S, S, 3, dtype=torch.uint8, device=self.device)
-        self._ctx.preprocess(f.data_ptr(), B, H, W, crop, out.data_ptr(), self._stream())
+        self._ctx.preprocess(f.data_ptr(), B, H, W, crop, out.data_ptr(), self._stream(), padded_resize)
         return out
 
     # ------------------------------------------------------------------ frozen instruction encoder (optional)

@@ -180,11 +180,15 @@ int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* t
                     const uint8_t* action_mask, int32_t B, const hvla_train_hyper* hyper, void* stream);
 int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_train_hyper* hyper, void* stream);
 
-/* Replaces: InferenceWrapper._resize_image without padded_resize (data/utils/hypervla_interface.py:89-121):
+/* Replaces: InferenceWrapper._resize_image (data/utils/hypervla_interface.py:89-121): optionally
+ * tf.image.resize_with_pad(image, 256, 320) (bilinear, zero padding; `padded_resize`), then
  * tf.image.resize(lanczos3, antialias=True) to image_size x image_size, optionally the centred sqrt(0.9)
  * tf.image.crop_and_resize (bilinear), then round / clip / uint8.  frames u8 [B, H, W, 3] (device) ->
- * images u8 [B, image_size, image_size, 3] (device), the input of hvla_step / hvla_encode_hidden.               */
-int hvla_preprocess(hvla_ctx* ctx, const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t crop, uint8_t* images,
+ * images u8 [B, image_size, image_size, 3] (device), the input of hvla_step / hvla_encode_hidden.
+ * flags: HVLA_PREPROCESS_CROP | HVLA_PREPROCESS_PAD.                                                              */
+#define HVLA_PREPROCESS_CROP 1
+#define HVLA_PREPROCESS_PAD 2
+int hvla_preprocess(hvla_ctx* ctx, const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t flags, uint8_t* images,
                     void* stream);
 
 /* Replaces: the frozen instruction encoder `LanguageTokenizer('t5-base')` that produces

@@ -377,6 +377,14 @@ def test_image_preprocessing_matches_restatement(mid):
         assert d.max() <= 1 and (d > 0).mean() < 1e-3, (H, W, crop, d.max(), (d > 0).mean())
     same = rng.integers(0, 256, (g.image_size, g.image_size, 3), dtype=np.uint8)
     np.testing.assert_array_equal(m.preprocess_images(same).cpu().numpy()[0], same)
+    # padded_resize: tf.image.resize_with_pad to 256 x 320 in front of the lanczos3 stage (hypervla_interface.py:90-95)
+    for (H, W), crop in (((240, 320), False), ((300, 200), True), ((256, 320), False)):
+        frames = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+        frames[1] = (np.linspace(0, 255, W)[None, :, None] * np.ones((H, 1, 3))).astype(np.uint8)
+        got = m.preprocess_images(frames, crop=crop, padded_resize=True).cpu().numpy()
+        want = np.stack([onp.preprocess_image(f, g.image_size, crop=crop, padded_resize=True) for f in frames])
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, ("padded", H, W, crop, d.max(), (d > 0).mean())
 
 
 @pytest.mark.timeout(600)

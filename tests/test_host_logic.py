@@ -104,14 +104,27 @@ def test_wrapper_chain_matches_golden(golden_dir, setup, ens):
         assert (np.abs(np.stack(acts)[:, -1]) > 0.5).sum() >= 15             # sticky gripper exercised
 
 
-def test_wrapper_rejects_padded_resize_and_bad_setup():
+def test_wrapper_rejects_bad_setup_and_sends_padded_resize_to_the_device():
     m = _FakeModel(np.zeros((1, 4, 7)))
     with pytest.raises(ValueError):
         InferenceWrapper(m, policy_setup="metaworld")
     w = InferenceWrapper(m, policy_setup="libero", pred_action_horizon=4, image_size=224, padded_resize=True)
     w.reset("t", {"language_instruction": {}}, {})
-    with pytest.raises(NotImplementedError):
-        w.step(np.zeros((480, 640, 3), np.uint8))
+    seen = {}
+
+    class _T:
+        def __init__(self, a): self.a = a
+        def __getitem__(self, i): return _T(self.a[i])
+        def cpu(self): return self
+        def numpy(self): return self.a
+
+    def fake_preprocess(frames, crop=False, padded_resize=False):
+        seen.update(crop=crop, padded_resize=padded_resize, shape=frames.shape)
+        return _T(np.zeros((1, 224, 224, 3), np.uint8))
+    m.preprocess_images = fake_preprocess
+    m.geometry = type("G", (), {"image_size": 224})()
+    w.step(np.zeros((480, 640, 3), np.uint8))
+    assert seen == {"crop": False, "padded_resize": True, "shape": (480, 640, 3)}
 
 
 def test_batched_ensembler_equals_unbatched():

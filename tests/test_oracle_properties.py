@@ -194,3 +194,23 @@ def test_image_preprocessing_restatement_properties():
     img = rng.integers(0, 256, (31, 31, 3)).astype(np.float32)
     c = onp.crop_and_resize_bilinear(img, 31)
     np.testing.assert_allclose(c[15, 15], img[15, 15], atol=1e-3)
+
+
+def test_resize_with_pad_restatement_properties():
+    """tf.image.resize_with_pad(image, 256, 320) restatement (hypervla_interface.py:90-95; parity unpinned): a 480 x 640
+    frame is halved to 240 x 320 and sits between 8 zero rows; halving with half-pixel centres averages 2 x 2 blocks; a
+    frame that already is 256 x 320 passes through; a tall frame is padded left and right instead."""
+    rng = np.random.default_rng(5)
+    f = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    p = onp.resize_with_pad_bilinear(f)
+    assert p.shape == (256, 320, 3) and p.dtype == np.float32
+    assert (p[:8] == 0).all() and (p[248:] == 0).all()
+    blocks = f.astype(np.float32).reshape(240, 2, 320, 2, 3).mean(axis=(1, 3))
+    np.testing.assert_allclose(p[8:248], blocks, atol=1e-4)
+    same = rng.integers(0, 256, (256, 320, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(onp.resize_with_pad_bilinear(same), same.astype(np.float32))
+    tall = np.full((512, 320, 3), 200, np.uint8)
+    q = onp.resize_with_pad_bilinear(tall)
+    assert (q[:, :80] == 0).all() and (q[:, 240:] == 0).all() and (q[:, 80:240] == 200).all()
+    out = onp.preprocess_image(f, 224, padded_resize=True)
+    assert out.shape == (224, 224, 3) and out.dtype == np.uint8 and out[:4].max() <= 2 and out[112].mean() > 60
