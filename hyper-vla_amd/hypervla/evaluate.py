@@ -211,18 +211,19 @@ class BatchEvaluator:
     sticky gripper, ...), but the model is stepped ONCE per timestep for all of them."""
 
     def __init__(self, model, policy_setup: str = "libero", pred_action_horizon: int = 4, action_ensemble: bool = True,
-                 crop: bool = False, image_size: Optional[int] = None):
+                 crop: bool = False, image_size: Optional[int] = None, padded_resize: bool = False):
         self.model = model
         self.kw = dict(policy_setup=policy_setup, horizon=1, pred_action_horizon=pred_action_horizon,
-                       image_size=image_size or model.geometry.image_size, action_ensemble=action_ensemble, crop=crop)
-        self.crop = crop
+                       image_size=image_size or model.geometry.image_size, action_ensemble=action_ensemble, crop=crop,
+                       padded_resize=padded_resize)
+        self.crop, self.padded_resize = crop, padded_resize
 
     def _frames_to_device(self, frames: np.ndarray):
         import torch
         g = self.model.geometry
-        if tuple(frames.shape[1:3]) == (g.image_size, g.image_size) and not self.crop:
+        if tuple(frames.shape[1:3]) == (g.image_size, g.image_size) and not self.crop and not self.padded_resize:
             return self.model._dev(frames, torch.uint8)
-        return self.model.preprocess_images(frames, crop=self.crop)          # lanczos3 (+ crop) on the device
+        return self.model.preprocess_images(frames, crop=self.crop, padded_resize=self.padded_resize)   # on the device
 
     def run(self, venv, tokenize: Callable[[List[str]], Dict[str, np.ndarray]], max_steps: int,
             instructions: Optional[List[str]] = None, reset_kwargs: Optional[dict] = None,
