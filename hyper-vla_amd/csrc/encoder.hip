@@ -769,8 +769,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       if (more) {
         tile_origin(vb, m0, n0);
         offsets(m0, n0);
+        __builtin_amdgcn_sched_barrier(0);            // the wait below counts the epilogue's stores as issued AFTER this DMA:
         stage(H0{}, 0); stage(H1{}, 0); stage(H2{}, 0); stage(H3{}, 0);
         stage(H0{}, 1); stage(H1{}, 1);
+        __builtin_amdgcn_sched_barrier(0);            // nothing may be scheduled across it in either direction
       }
     }
     if constexpr (FL & 32) {                          // diagnostics: no epilogue (one lane keeps the accumulators alive)
