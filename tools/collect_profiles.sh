@@ -29,4 +29,7 @@ HVLA_VARIANTS=5,9 python tools/gemm_bench.py 256 > $P/r1_gemm_isolated.txt 2>/de
 HVLA_DBG_MSHRINK=256 HVLA_VARIANTS=9,27 python tools/gemm_bench.py 256 >> $P/r1_gemm_isolated.txt 2>/dev/null   # whole rounds: one launch per tile vs persistent
 python tools/bgemm_bench.py > $P/r1_train_gemm_isolated.txt 2>/dev/null
 python tools/determinism_probe.py > $P/r1_determinism.txt 2>/dev/null
+{ echo "# default (persistent 256x256 + gemm64 tail rows)"; python tools/gemm_race_screen.py 2>/dev/null
+  echo "# HVLA_GEMM=ring (lockstep ring kernel, per-lane-column epilogue, W as first MFMA operand)"; HVLA_GEMM=ring python tools/gemm_race_screen.py 2>/dev/null
+  echo "# HVLA_NO_PERSIST=1 HVLA_NO_PEEL=1 (one launch per tile, tail rows in the 256x256 grid)"; HVLA_NO_PERSIST=1 HVLA_NO_PEEL=1 python tools/gemm_race_screen.py 2>/dev/null; } > $P/r1_gemm_race_screen.txt
 ls $P
