@@ -85,23 +85,29 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   float u = k0 * (x + k1 * x * x * x);
   return 0.5f * x * (1.0f + tanhf(u));
 }
-// exact-erf GELU (HF ACT2FN["gelu"]).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32
-// round-off level) instead of libm erff: ~14 VALU ops with one v_rcp and one v_exp, which matters
-// because the fc1 epilogue applies it to B*257*3072 values per layer.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
+// exact-erf GELU (HF ACT2FN["gelu"]).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 round-off level)
+// instead of libm erff, which matters because the fc1 epilogue applies it to B*257*3072 values per layer with the matrix
+// pipe idle.  Written for pairs so that everything except v_rcp / v_exp is a packed f32 instruction, and in the even form
+//   gelu(x) = max(x, 0) - (|x| / 2) P(t) exp(-x^2 / 2),   t = 1 / (1 + p |x| / sqrt 2),
+// (x erf(x / sqrt 2) is even in x) which needs no sign transfer and has no cancellation for negative x: 15 issue slots
+// per element, 8 of them the two quarter-rate transcendentals.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 d = __builtin_elementwise_fma(ax, f32x2{0.2316418882f, 0.2316418882f}, f32x2{1.f, 1.f});   // 0.3275911 / sqrt 2
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 p = __builtin_elementwise_fma(t, f32x2{0.5307027145f, 0.5307027145f}, f32x2{-0.7265760135f, -0.7265760135f});   // A-S coefficients / 2
+  p = __builtin_elementwise_fma(p, t, f32x2{0.7107068705f, 0.7107068705f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-0.142248368f, -0.142248368f});
+  p = __builtin_elementwise_fma(p, t, f32x2{0.127414796f, 0.127414796f});
   p *= t;
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  const float r = fmaf(-p, e, 1.0f);
-  return copysignf(r, x);
+  const f32x2 w = x * x;
+  const f32x2 ea = w * f32x2{-0.7213475204444817f, -0.7213475204444817f};                               // -log2(e) / 2
+  const f32x2 e = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+  const f32x2 h = ax * p;
+  const f32x2 m = __builtin_elementwise_max(x, f32x2{0.f, 0.f});
+  return __builtin_elementwise_fma(-h, e, m);
 }
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erf_fast(x * 0.7071067811865476f));
-}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
 
 }  // namespace hvla

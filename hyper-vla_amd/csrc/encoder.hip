@@ -226,8 +226,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
         else t[c] = acc[c][mp + u] + b4[c];
         if constexpr (EPI == EPI_QKV) t[c] *= q;
         if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) t[c][r] = gelu_erf(t[c][r]);
+          const f32x2 g0 = gelu_erf2(f32x2{t[c][0], t[c][1]}), g1 = gelu_erf2(f32x2{t[c][2], t[c][3]});
+          t[c] = f32x4{g0[0], g0[1], g1[0], g1[1]};
         }
       }
 #pragma unroll
