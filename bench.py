@@ -307,7 +307,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": world * B, "encoder": "DINOv2-base (reference parity, E=768)" if a.encoder == "base" else "DINOv2-small (E=384)",
                    "parallelism": f"episode-dp{world} (no collectives)",
                    "encoder_operands": a.enc_dtype, "policy_operands": "split-bf16 (bf16x3)",
-                   "launch": "hipGraph replay" if a.graph else "eager (about 140 launches per step)",
+                   "launch": "hipGraph replay" if a.graph else f"eager (about {140 if B * g.seq > 2047 else 90} launches per step)",
                    "streams": a.streams,
                    "ensemble": "device-side un-normalise + temporal ensemble (history = horizon) inside the step"
                                if ens is not None else "not in the step"},
