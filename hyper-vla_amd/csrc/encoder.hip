@@ -455,95 +455,11 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 256x256x64 block tile, 8 waves (2 along M x 4 along N, 128x64 each), operands staged global -> LDS by
-// LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction).  The LDS image is
-// lane-linear (hardware writes base + lane*16), so the bank swizzle chunk ^= (row & 7) is applied to the
-// per-lane SOURCE address and again on the ds_read_b128 address (guide §5.4 rule 21): 128-B rows then
-// read conflict-free.  Two LDS buffers (128 KiB): the DMA of K-tile t+1 is issued before the MFMAs of
-// tile t and drained (vmcnt(0)) at the single barrier per K-tile.
+// 256x256x64 block tiles, 8 waves (2 along M x 4 along N, 128x64 each), operands staged global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction).  The LDS image is lane-linear (hardware
+// writes base + lane*16), so the bank swizzle chunk ^= (row & 7) is applied to the per-lane SOURCE address and again on
+// the ds_read_b128 address (guide §5.4 rule 21): 128-B rows then read conflict-free.
 constexpr int HBM_ = 256, HBN_ = 256;
-template <typename Op, int EPI, int ABL = 0>   // ABL (diagnostics only): 1 = no DMA in the loop, 2 = no MFMA
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
-  using T = typename Op::elem;
-  using X8 = typename Op::x8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nbm = (g.M + HBM_ - 1) / HBM_, nbn = g.N / HBN_;
-  int bid = blockIdx.x;
-  {
-    // blocks b and b+8 share an XCD (guide T1): give each XCD a contiguous run of logical tile ids ...
-    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
-  // ... and order the ids so that the ~32 tiles an XCD runs at once form a (8 M-tiles x GN N-tiles) patch:
-  // its A and W K-slices then stay in that XCD's 4 MiB L2 instead of being re-fetched from HBM/MALL.
-  const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
-  const int per_sc = nbm * GN;
-  const int sc = bid / per_sc, rem = bid % per_sc;
-  const int bm = rem / GN, bn = sc * GN + rem % GN;
-  const int m0 = bm * HBM_, n0 = bn * HBN_;
-  const T* A = reinterpret_cast<const T*>(g.A);
-  const T* W = reinterpret_cast<const T*>(g.W);
-  // ---- LDS-DMA staging: instruction j of wave w fills rows [64 j + 8 w, +8), lane -> (row = lane >> 3,
-  // LDS chunk = lane & 7) and fetches global chunk (lane & 7) ^ (row & 7)
-  const int srow = wave * 8 + (lane >> 3);
-  const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
-  const T* asrc[4];
-  const T* wsrc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + 64 * j + srow;
-    m = m < g.M ? m : g.M - 1;
-    asrc[j] = A + (size_t)m * g.K + sch;
-    wsrc[j] = W + (size_t)(n0 + 64 * j + srow) * g.K + sch;
-  }
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * 65536 + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(base + 32768 + j * 8192), 16, 0, 0);
-    }
-  };
-  f32x4 acc[4][8];   // [n-tile][m-tile]
-  const int fr = lane & 15, fq = lane >> 4;
-  const int sw0 = ((fq) ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
-  const int a_off = (wm * 128 + fr) * 128, w_off = 32768 + (wn * 64 + fr) * 128;
-  const int KT = g.K / 64;
-  stage(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT && ABL != 1) stage(buf ^ 1, kt + 1);
-    const char* lb = smem + buf * 65536;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int sw = kk ? sw1 : sw0;
-      X8 fa[8], fw[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fw[t] = *reinterpret_cast<const X8*>(lb + w_off + t * 2048 + sw);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) fa[t] = *reinterpret_cast<const X8*>(lb + a_off + t * 2048 + sw);
-      if constexpr (ABL != 2) {
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = Op::mma16(fw[nt], fa[mt], acc[nt][mt]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(fw[t]));
-#pragma unroll
-        for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(fa[t]));
-      }
-    }
-    __syncthreads();     // vmcnt(0) for the DMA of tile kt+1 + all waves done reading tile kt
-  }
-  gemm_epilogue<Op, EPI, 4, 8>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
-}
 
 // ------------------------------------------------------------------------------------------------
 // 256x256x64 tile, 8 waves, FOUR PHASES per K-tile with the two wave rows running half a phase apart (guide §5 "256^2
@@ -557,7 +473,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 //     3 and 4 of tile t, its W halves in phases 1 and 2 of tile t+1.  The wait in phase 4 is the constant vmcnt(4): tile
 //     t+1 has landed, the two A halves of tile t+2 stay in flight across the barriers.
 //   * the last two K-tiles are peeled (nothing is staged past the end, the wait constants stay immediates).
-// LDS image and swizzle are those of gemm256_kernel (128-byte rows, chunk ^= row & 7 on the source and on the read).
+// LDS image and swizzle as described above (128-byte rows, chunk ^= row & 7 on the source and on the read).
 // FL (diagnostics): 1 no stagger, 2 s_setprio(1) around the MFMA clusters (measured 10 % SLOWER here, off by default),
 // 4 no DMA in the loop, 8 no MFMA, 16 no fragment reads in the loop, 32 no epilogue
 template <typename Op, int EPI, bool PEEL = true, int FL = 0, bool PERSIST = false>
@@ -1423,8 +1339,6 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     SETA((gemm_kernel<Op, EPI_PATCH>)) SETA((gemm_kernel<Op, EPI_QKV>)) SETA((gemm_kernel<Op, EPI_GELU>))
     SETA((gemm_kernel<Op, EPI_RES>)) SETA((attention_kernel<Op>))
-    SETA((gemm256_kernel<Op, EPI_PATCH>)) SETA((gemm256_kernel<Op, EPI_QKV>)) SETA((gemm256_kernel<Op, EPI_GELU>))
-    SETA((gemm256_kernel<Op, EPI_RES>))
     SETA((gemm256r_kernel<Op, EPI_PATCH>)) SETA((gemm256r_kernel<Op, EPI_QKV>)) SETA((gemm256r_kernel<Op, EPI_GELU>))
     SETA((gemm256r_kernel<Op, EPI_RES>))
     SETA((gemm256p_kernel<Op, EPI_PATCH>)) SETA((gemm256p_kernel<Op, EPI_QKV>)) SETA((gemm256p_kernel<Op, EPI_GELU>))
@@ -1436,7 +1350,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
 #undef SETA
     attr = true;
   }
-  static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "simple" | "phase" | "ring" select a kernel
+  static const char* gsel = getenv("HVLA_GEMM");     // diagnostics: "128" | "ring" select another kernel
   static const bool phased = !(gsel && !strcmp(gsel, "ring"));
   static const bool nopeel = getenv("HVLA_NO_PEEL") != nullptr;
   static const bool nopersist = getenv("HVLA_NO_PERSIST") != nullptr;
@@ -1452,7 +1366,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
   }
   bool fc1_main_closed = false;   // profiler mode 1: the fc1 bracket covers the 256x256 launch only (see gemm)
-  auto gemm = [&](auto kern, auto kern64, auto kern256, auto kern256r, auto kern256p, auto kern256pp, const void* A, const void* Wt, int Mm, int N, int K,
+  auto gemm = [&](auto kern, auto kern64, auto kern256r, auto kern256p, auto kern256pp, const void* A, const void* Wt, int Mm, int N, int K,
                   const float* bias, const float* aux, void* out, int qcols, bool is_res = false, bool peel = true,
                   int main_cat = -1) {
     GemmArgs a{A, Wt, Mm, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
@@ -1488,7 +1402,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       } else {
         hipLaunchKernelGGL(kern256p, dim3(nbm * nbn), dim3(512), 131072, st, a);
       }
-    } else if (big && K >= 256 && fits32 && !(gsel && !strcmp(gsel, "simple"))) {
+    } else if (big && K >= 256 && fits32) {
       int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
       // tail-round fix (in-place residual epilogue only): when a few tiles spill into an extra round on the
       // 256 CUs, split those along K over otherwise idle CUs
@@ -1505,9 +1419,6 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
         }
       }
       hipLaunchKernelGGL(kern256r, dim3(nb), dim3(512), 131072, st, a);
-    } else if (big) {
-      const int nb = ((Mm + HBM_ - 1) / HBM_) * (N / HBN_);
-      hipLaunchKernelGGL(kern256, dim3(nb), dim3(512), 131072, st, a);
     } else if (Mm <= g64_maxm && fits32 && N % SBN == 0 && K % 64 == 0) {
       hipLaunchKernelGGL(kern64, dim3(((Mm + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, a);
     } else {
@@ -1524,7 +1435,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     hipLaunchKernelGGL(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
                        g.image_size, g.patch, g.grid(), Kp);
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * E + 255) / 256), dim3(256), 0, st, ws.x, w.pos, B, S, E);
-    gemm(gemm_kernel<Op, EPI_PATCH>, gemm64_kernel<Op, EPI_PATCH>, gemm256_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH, true, 0, true>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0, false, false);
+    gemm(gemm_kernel<Op, EPI_PATCH>, gemm64_kernel<Op, EPI_PATCH>, gemm256r_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH>, gemm256p_kernel<Op, EPI_PATCH, true, 0, true>, ws.g, w.w_patch, B * P, E, Kp, w.b_patch, w.pos, ws.x, 0, false, false);
   }
   pf.end(0, st);
   const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
@@ -1536,14 +1447,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                        L.ln1_b, M, E, S);
     pf.end(1, st);
     pf.begin(2, st);
-    gemm(gemm_kernel<Op, EPI_QKV>, gemm64_kernel<Op, EPI_QKV>, gemm256_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV, true, 0, true>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
+    gemm(gemm_kernel<Op, EPI_QKV>, gemm64_kernel<Op, EPI_QKV>, gemm256r_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV>, gemm256p_kernel<Op, EPI_QKV, true, 0, true>, ws.h, L.wqkv, M, 3 * E, E, L.bqkv, nullptr, ws.qkv, E);
     pf.end(2, st);
     pf.begin(3, st);
     hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H);
     pf.end(3, st);
     pf.begin(4, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES, true, 0, true>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES, true, 0, true>, ws.h, L.wo, M, E, E, L.bo, L.ls1, ws.x, 0, true);
     pf.end(4, st);
     pf.begin(1, st);
     hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln2_s,
@@ -1551,11 +1462,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     pf.end(1, st);
     fc1_main_closed = false;
     pf.begin(5, st);   // in "dominant kernel only" mode the bracket is closed right behind the main launch (inside gemm)
-    gemm(gemm_kernel<Op, EPI_GELU>, gemm64_kernel<Op, EPI_GELU>, gemm256_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU, true, 0, true>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0, false,
+    gemm(gemm_kernel<Op, EPI_GELU>, gemm64_kernel<Op, EPI_GELU>, gemm256r_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU>, gemm256p_kernel<Op, EPI_GELU, true, 0, true>, ws.h, L.w1, M, F, E, L.b1, nullptr, ws.g, 0, false,
          true, 5);
     if (!(pf.mode == 1 && fc1_main_closed)) pf.end(5, st);
     pf.begin(6, st);
-    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES, true, 0, true>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
+    gemm(gemm_kernel<Op, EPI_RES>, gemm64_kernel<Op, EPI_RES>, gemm256r_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES>, gemm256p_kernel<Op, EPI_RES, true, 0, true>, ws.g, L.w2, M, E, F, L.b2, L.ls2, ws.x, 0, true);
     pf.end(6, st);
   }
   pf.begin(1, st);
@@ -1580,17 +1491,10 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
   auto launch = [&]() {
     const int nb256 = ((M + 255) / 256) * (N / 256), nb128 = ((M + 127) / 128) * (N / 128);
     const size_t gsm = (size_t)2 * (GBM + GBN) * GLD * 2;
-#define L256(E, AB) hipLaunchKernelGGL((gemm256_kernel<Op, E, AB>), dim3(nb256), dim3(512), 131072, st, a)
     if (variant == 0) {
       if (epi == EPI_QKV) hipLaunchKernelGGL((gemm_kernel<Op, EPI_QKV>), dim3(nb128), dim3(256), gsm, st, a);
       else if (epi == EPI_GELU) hipLaunchKernelGGL((gemm_kernel<Op, EPI_GELU>), dim3(nb128), dim3(256), gsm, st, a);
       else hipLaunchKernelGGL((gemm_kernel<Op, EPI_RES>), dim3(nb128), dim3(256), gsm, st, a);
-    } else if (variant == 1) {
-      if (epi == EPI_QKV) L256(EPI_QKV, 0); else if (epi == EPI_GELU) L256(EPI_GELU, 0); else L256(EPI_RES, 0);
-    } else if (variant == 2) {
-      L256(EPI_QKV, 1);
-    } else if (variant == 3) {
-      L256(EPI_QKV, 2);
     } else if (variant >= 6 && variant <= 8) {
       if (variant == 6) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 2, 1>), dim3(nb256), dim3(512), 131072, st, a);
       if (variant == 7) hipLaunchKernelGGL((gemm256r_kernel<Op, EPI_QKV, 2, 2>), dim3(nb256), dim3(512), 131072, st, a);
@@ -1632,12 +1536,9 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
       if (epi == EPI_QKV) L256R4(EPI_QKV); else if (epi == EPI_GELU) L256R4(EPI_GELU); else L256R4(EPI_RES);
 #undef L256R4
     }
-#undef L256
   };
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<Op, EPI_QKV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<Op, EPI_QKV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<Op, EPI_QKV, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -11,7 +11,7 @@ lib = m._ctx.lib
 lib.hvla_debug_gemm.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_float)]
 M = B * 257 - int(os.environ.get('HVLA_DBG_MSHRINK', '0'))
 shapes = {"qkv": (M, 2304, 768, 1), "out": (M, 768, 768, 3), "fc1": (M, 3072, 768, 2), "fc2": (M, 768, 3072, 3)}
-names = {0: "128x128 regstage", 1: "256x256 lds-dma", 2: "256 no-DMA-in-loop", 3: "256 no-MFMA", 4: "ring5 8 waves", 5: "256 ring4", 6: "ring4 no-DMA", 7: "ring4 no-MFMA", 8: "ring4 DMA-only", 9: "phased, peeled tail", 10: "phased, clamped tail", 11: "phased no stagger", 12: "phased with setprio", 13: "phased no DMA in loop", 14: "phased no MFMA", 15: "phased no frag reads", 16: "phased barriers only", 17: "phased MFMA only", 18: "phased frag reads only", 19: "phased DMA only", 20: "phased MFMA only, no stagger", 21: "phased no epilogue", 22: "phased old epilogue (QKV)", 23: "phased stores kept in L2", 24: "phased old epilogue (GELU)", 25: "phased old epilogue (RES)", 27: "phased, persistent"}
+names = {0: "128x128 regstage", 4: "ring5 8 waves", 5: "256 ring4", 6: "ring4 no-DMA", 7: "ring4 no-MFMA", 8: "ring4 DMA-only", 9: "phased, peeled tail", 10: "phased, clamped tail", 11: "phased no stagger", 12: "phased with setprio", 13: "phased no DMA in loop", 14: "phased no MFMA", 15: "phased no frag reads", 16: "phased barriers only", 17: "phased MFMA only", 18: "phased frag reads only", 19: "phased DMA only", 20: "phased MFMA only, no stagger", 21: "phased no epilogue", 22: "phased old epilogue (QKV)", 23: "phased stores kept in L2", 24: "phased old epilogue (GELU)", 25: "phased old epilogue (RES)", 27: "phased, persistent"}
 for nm, (M_, N, K, epi) in shapes.items():
     for variant in (tuple(int(v) for v in os.environ["HVLA_VARIANTS"].split(",")) if "HVLA_VARIANTS" in os.environ else (5, 4)):
         if 6 <= variant <= 8 and nm != "qkv" and nm != "fc2":
