@@ -561,6 +561,29 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ o
   unsafeAtomicAdd(out + (long)b * ostride + n, s);
 }
 
+// the same for 16-byte aligned rows with N % 4 == 0: a thread owns 4 columns (1 KiB per wave and row), 32 rows per chunk,
+// eight row loads in flight
+__global__ void colsum4_kernel(const float* __restrict__ x, float* __restrict__ out, long ostride, int R, int rows_used,
+                               int N, int nb) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) * 4, b = blockIdx.y;
+  if (n >= N || b >= nb) return;
+  const int r0 = blockIdx.z * 32, r1 = r0 + 32 < rows_used ? r0 + 32 : rows_used;
+  const float* p = x + ((long)b * R + r0) * N + n;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  int r = r0;
+  for (; r + 8 <= r1; r += 8, p += 8L * N) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (long)u * N);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; r < r1; ++r, p += N) s += *reinterpret_cast<const f32x4*>(p);
+  float* o = out + (long)b * ostride + n;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) unsafeAtomicAdd(o + c, s[c]);
+}
+
 // x0 assembly: rows < P already hold tokens.Wp + bp; row P = 0; += pos  (base_vit.py:182-204)
 __global__ void x0_finish_kernel(float* __restrict__ x, const float* __restrict__ pos, long pstride, int S, int D, int nb) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -908,7 +931,10 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
     else bgemm(st, true, false, BG{X, dY, dW, nullptr, K, N, S, K, N, N, (long)S * K, 0, (long)S * N, 0, gs, 0, 0, 1, 1.f, 1}, nb);
   };
   auto bgrad = [&](const float* dY, int N, float* dB) {
-    if (shared) KL(colsum_kernel, dim3((N + 63) / 64, 1, (rows + 63) / 64), dim3(64), dY, dB, 0, rows, rows, N, 1);
+    const bool v4 = N % 4 == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
+    if (shared && v4) KL(colsum4_kernel, dim3((N / 4 + 63) / 64, 1, (rows + 31) / 32), dim3(64), dY, dB, 0, rows, rows, N, 1);
+    else if (shared) KL(colsum_kernel, dim3((N + 63) / 64, 1, (rows + 63) / 64), dim3(64), dY, dB, 0, rows, rows, N, 1);
+    else if (v4) KL(colsum4_kernel, dim3((N / 4 + 63) / 64, nb, (S + 31) / 32), dim3(64), dY, dB, gs, S, S, N, nb);
     else KL(colsum_kernel, dim3((N + 63) / 64, nb, (S + 63) / 64), dim3(64), dY, dB, gs, S, S, N, nb);
   };
   auto ln_bwd = [&](const float* x, const float* dy, const float* mean, const float* rstd, const float* sc, float* gs_, float* gb_) {
