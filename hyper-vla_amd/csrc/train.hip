@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
 // 4 waves as 2 x 2, BM x BN in {128 x 128, 64 x 64}, k steps of 32 with three steps of global loads in flight.
 // ------------------------------------------------------------------------------------------------
 // Staging of one BR x 32 operand tile (f32 in memory -> hi / lo bf16 planes in LDS), two flavours:
-//   T = false  source is k-contiguous (rows of 32 floats): LDS image [row][40]; fragments by ds_read_b128
+//   T = false  source is k-contiguous (rows of 32 floats): LDS image [row][32] with XOR-swizzled 16-byte chunks; fragments by ds_read_b128
 //   T = true   source is row-contiguous (memory [k][row]): LDS image [k][BR + 32], no transposition while staging;
 //              the fragment's k-in-lane order comes from ds_read_b64_tr_b16 (two per plane and k chunk)
 // Either way a thread moves float4's along the contiguous dimension (scalar fallback for unaligned / edge pieces).
@@ -162,7 +162,8 @@ __device__ __forceinline__ void stage_store(__bf16* __restrict__ hi, __bf16* __r
 #pragma unroll
   for (int j = 0; j < BR * 8 / 256; ++j) {
     const int idx = threadIdx.x + j * 256;
-    const int o = T ? (idx / (BR / 4)) * (BR + 32) + (idx % (BR / 4)) * 4 : (idx >> 3) * 40 + (idx & 7) * 4;
+    const int o = T ? (idx / (BR / 4)) * (BR + 32) + (idx % (BR / 4)) * 4
+                    : (idx >> 3) * 32 + ((((idx & 7) >> 1) ^ ((idx >> 4) & 3)) << 3) + (idx & 1) * 4;   // row = idx >> 3, see load_frag
     bf16x4 h, l;
     __bf16 a, b;
 #ifdef HVLA_ABL_NOSPLIT      // timing ablation only (wrong numbers): what a pre-split operand would cost to stage
@@ -191,7 +192,10 @@ template <bool T, int BR>
 __device__ __forceinline__ Split8 load_frag(const __bf16* hi, const __bf16* lo, int rb, int kk, int lane) {
   Split8 f;
   if (!T) {
-    const int o = (rb + (lane & 31)) * 40 + kk + (lane >> 5) * 8;
+    // 64-byte rows, the 16-byte chunk index XORed with (row >> 1) & 3: the 8-byte stores of a half-wave (4 rows) and the
+    // 16-byte reads of 8 consecutive rows both spread over all 64 banks (the padded [row][40] image had 2-way store conflicts)
+    const int row = rb + (lane & 31);
+    const int o = row * 32 + ((((kk >> 3) + (lane >> 5)) ^ ((row >> 1) & 3)) << 3);
     f.hi = *reinterpret_cast<const bf16x8*>(hi + o);
     f.lo = *reinterpret_cast<const bf16x8*>(lo + o);
   } else {
@@ -210,7 +214,7 @@ template <bool TA, bool TB, int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, IN = WN / 32;
   constexpr bool SA = TA, SB = !TB;                       // staging flavour: row-contiguous source?
-  constexpr int NA = SA ? 32 * (BM + 32) : BM * 40, NB = SB ? 32 * (BN + 32) : BN * 40;
+  constexpr int NA = SA ? 32 * (BM + 32) : BM * 32, NB = SB ? 32 * (BN + 32) : BN * 32;
   // k steps of global loads in flight (register stages): three float4 stages, or two when every piece is 4 dwords
   // (the 6-bit vmcnt could not count three of those)
   constexpr int NST = VEC ? 3 : 2;
