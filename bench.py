@@ -1,7 +1,9 @@
 """bench.py — headline benchmark of the HyperVLA action-prediction path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--batch 256] [--enc-dtype f16|bf16]
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 works as typed: without WORLD_SIZE in the environment the script starts its own ranks with
+     `python -m torch.distributed.run --nproc-per-node N ...` as a CHILD process before anything touches the GPU;
+     under a launcher that already set RANK / WORLD_SIZE it is one of the ranks.)
 
 One "step" = one `sample_actions` over one batch of synthetic OXE-shaped observations: uint8 224x224
 images -> DINOv2-base (in the loop, as the reference runs it, base_vit.py:109-133) -> generated vit_t
@@ -130,6 +132,28 @@ def finetune_bench(a, model, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` typed directly (no launcher): start one rank per GPU as children of this process,
+    which has not touched the GPU (no HIP call yet; a process that has must never exec or fork GPU work), let rank 0's
+    JSON line through on the inherited stdout and return the launcher's exit code."""
+    import socket
+    import subprocess
+    if os.environ.get("HVLA_BENCH_SHARE_GPU") != "1":
+        have = torch.cuda.device_count()             # counting devices does not initialise the GPU
+        if have < n:
+            print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
+            return 2
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,10 +177,12 @@ def main():
                     help="with --finetune: fine_tune_pretrained_image_encoder=True (README.md:55)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     # test hook only (tests/test_gpu_parity.py): all ranks on GPU 0 over gloo, so that the N > 1 control flow can be run on
     # a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
     share = os.environ.get("HVLA_BENCH_SHARE_GPU") == "1"

@@ -578,6 +578,26 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_starts_its_own_ranks_when_typed_without_a_launcher():
+    """`python bench.py --gpus 2 ...` exactly as the driver types the N = 1 command (no torch.distributed.run in front, no
+    WORLD_SIZE): the script spawns the ranks itself and one JSON line with n_gpus = 2 comes out (missing #1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["HVLA_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["value"] > 0
+
+
+@pytest.mark.gpu
 def test_tokens_are_the_same_whichever_gemm_kernel_computes_them():
     """Batch sizes on both sides of the kernel choices in csrc/encoder.hip -- gemm64_kernel up to 2047 rows (B <= 7), the
     256x256 kernel above, with and without peeled tail rows -- give an image the same patch tokens, bit for bit."""

@@ -59,3 +59,33 @@ def test_two_ranks_gloo():
     assert t0 == t1 == 0.5                                       # max over ranks
     assert g0 == g1 and g0[0] != g0[1]                           # different episodes on different ranks
     assert v0 == v1 == 2 * 3 * 10 / 0.5
+
+
+def test_bench_self_launch_builds_the_launcher_command(monkeypatch):
+    """`python bench.py --gpus 8` with no launcher: the ranks are started as a child `torch.distributed.run` on the loopback
+    interface with the caller's own arguments, and its exit code is what the script returns; asking for more GPUs than the
+    node has is refused before anything is spawned."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--batch", "1024", "--steps", "5"])
+    monkeypatch.setenv("HVLA_BENCH_SHARE_GPU", "1")
+    assert bench.self_launch(8) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "8", "--batch", "1024", "--steps", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.delenv("HVLA_BENCH_SHARE_GPU")
+    seen.clear()
+    assert bench.self_launch(8) == 2 and not seen          # this container exposes no GPU: refused, nothing spawned
