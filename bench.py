@@ -29,16 +29,13 @@ import torch         # noqa: E402
 PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
-def fc1_main_rows(M, N, ncu):
-    """Rows the timed gemm256p_kernel launch of fc1 covers: csrc/encoder.hip peels the last M-tile rows onto gemm64_kernel
-    when that leaves the 256x256 grid a whole number of rounds of `ncu` workgroups (same rule as there)."""
-    if M < 1024 or M <= 2047 or N % 256:
-        return M
-    nbm, nbn = (M + 255) // 256, N // 256
-    rem = (nbm * nbn) % ncu
-    r = (rem + nbn - 1) // nbn
-    if rem > 0 and r * 8 <= nbm and ((nbm - r) * nbn) % ncu == 0 and M % 256 == 0:
-        return (nbm - r) * 256
+def fc1_main_rows(B, g):
+    """Rows the timed gemm256p_kernel launch of fc1 covers: csrc/encoder.hip tiles the batch image by image (tile row b =
+    the 256 patch rows of image b; the B CLS rows run in gemm64_kernel right behind it) when a batch has more than 2047
+    rows; below that the whole GEMM is one gemm64_kernel launch."""
+    M = B * (g.patches + 1)
+    if g.patches == 256 and M > 2047 and g.enc_mlp % 256 == 0:
+        return B * g.patches
     return M
 
 
@@ -318,7 +315,7 @@ def main():
     dom_ms = dom[0] / max(dom[1], 1)
     parts = 2 if (a.streams == 2 and B >= 64) else 1       # episodes per fc1 launch = B / parts
     rows = (B // parts) * (g.patches + 1)
-    main_rows = fc1_main_rows(rows, g.enc_mlp, torch.cuda.get_device_properties(dev).multi_processor_count)
+    main_rows = fc1_main_rows(B // parts, g)
     fc1_flops = 2.0 * main_rows * g.enc_dim * g.enc_mlp    # of the timed launch (the 256x256 grid; tail rows run in gemm64_kernel)
     achieved = fc1_flops / (dom_ms * 1e-3) / 1e12
     ms_per_step = elapsed / a.steps * 1e3
@@ -332,7 +329,9 @@ def main():
                                "[4,7] action chunk); 1 action = 1 sample-step",
                    "batch_per_gpu": B, "global_batch": world * B, "encoder": "DINOv2-base (reference parity, E=768)" if a.encoder == "base" else "DINOv2-small (E=384)",
                    "parallelism": f"episode-dp{world} (no collectives)",
-                   "encoder_operands": a.enc_dtype, "policy_operands": "split-bf16 (bf16x3)",
+                   "encoder_operands": a.enc_dtype + " (+ per-image first-order compensation of the weight rounding, "
+                                       "kernel_ms_per_step.weight_rounding_compensation)",
+                   "policy_operands": "split-bf16 (bf16x3)",
                    "launch": "hipGraph replay" if a.graph else f"eager (about {140 if B * g.seq > 2047 else 90} launches per step)",
                    "streams": a.streams,
                    "ensemble": "device-side un-normalise + temporal ensemble (history = horizon) inside the step"

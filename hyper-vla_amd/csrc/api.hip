@@ -53,6 +53,13 @@ inline uint16_t f2h(float f) {
 
 }  // namespace
 
+// floats of column-sum scratch per image: two halves of the widest activation row (GELU outputs), or one partial per
+// 32-row chunk of a LayerNorm output
+static size_t parts_per_image(const Geom& g) {
+  const size_t a = (size_t)2 * (g.enc_mlp > g.E ? g.enc_mlp : g.E), b = (size_t)((g.S() + 31) / 32) * g.E;
+  return a > b ? a : b;
+}
+
 struct hvla_weights {
   int B = 0;
   DevBuf wh, wl, vf, ctx, ring, count;
@@ -70,10 +77,10 @@ struct hvla_ctx {
   DevBuf hn_f32;                 // context-encoder parameters, natural flax layout
   CtxParams ctxp{};
   DevBuf wcat_hi, wcat_lo, bcat, perm;
-  DevBuf enc16, encf32;          // encoder matrices (16-bit) and vectors (f32)
+  DevBuf enc16, encd16, encf32;  // encoder matrices (16-bit), their rounding residues x 4096 (16-bit) and vectors (f32)
   EncWeights encw{};
   // workspaces (sized for cfg.max_batch)
-  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, tokens, flags;
+  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_parts, ws_corr, tokens, flags;
   Profiler prof;
   // cfg.streams == 2: helper stream and fork / join events of hvla_step
   hipStream_t side = nullptr;
@@ -158,6 +165,7 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   A(ctx->ctx_hi, Bm * g.C * 2); A(ctx->ctx_lo, Bm * g.C * 2); A(ctx->ctx_f32, Bm * g.C * 4);
   A(ctx->ws_x, Bm * S * E * 4); A(ctx->ws_h, Bm * S * E * 2); A(ctx->ws_qkv, Bm * S * 3 * E * 2);
   A(ctx->ws_g, gbytes); A(ctx->tokens, Bm * P * E * 4); A(ctx->flags, 64 * sizeof(int));
+  A(ctx->ws_parts, Bm * parts_per_image(g) * 4); A(ctx->ws_corr, Bm * (F > 3 * E ? F : 3 * E) * 4);
   if (e != hipSuccess) return HVLA_E_ARENA_FULL;
   if (c->streams == 2) {
     if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
@@ -328,7 +336,7 @@ int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
     const bool bf = ctx->cfg.enc_dtype == HVLA_ENC_BF16;
     auto cv = [&](float f) { return bf ? f2bf(f) : f2h(f); };
     const size_t per_layer16 = (size_t)3 * E * E + (size_t)E * E + (size_t)2 * E * Fe;
-    std::vector<uint16_t> w16((size_t)E * Kp + per_layer16 * g.enc_layers);
+    std::vector<uint16_t> w16((size_t)E * Kp + per_layer16 * g.enc_layers), d16(w16.size(), 0);
     const size_t per_layerf = (size_t)3 * E + E + Fe + E + 6 * (size_t)E;
     std::vector<float> wf((size_t)E + (size_t)S * E + 2 * (size_t)E + per_layerf * g.enc_layers);
     size_t o16 = 0, of = 0;
@@ -368,9 +376,16 @@ int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
     for (size_t i = 0; i < (size_t)S * E; ++i) wf[offf.back() + i] = e_pos[i] + (i < (size_t)E ? e_cls[i] : 0.f);
     markf(E); memcpy(&wf[offf.back()], e_lns, E * 4);
     markf(E); memcpy(&wf[offf.back()], e_lnb, E * 4);
-    auto tr = [&](const float* src, int K, int N, size_t dst) {   // flax [K][N] -> [N][K] 16-bit
+    // flax [K][N] -> [N][K] 16-bit, and what the rounding dropped (x 4096: stays in the normal range of fp16) for the
+    // per-image compensation of the encoder GEMMs (encoder.hip corr_kernel)
+    auto tr = [&](const float* src, int K, int N, size_t dst) {
       for (int nn = 0; nn < N; ++nn)
-        for (int k = 0; k < K; ++k) w16[dst + (size_t)nn * K + k] = cv(src[(size_t)k * N + nn]);
+        for (int k = 0; k < K; ++k) {
+          const float wv = src[(size_t)k * N + nn];
+          const uint16_t h = cv(wv);
+          w16[dst + (size_t)nn * K + k] = h;
+          d16[dst + (size_t)nn * K + k] = cv((wv - back(h)) * 4096.f);
+        }
     };
     for (int i = 0; i < g.enc_layers; ++i) {
       const LSrc& s = ls[i];
@@ -388,21 +403,25 @@ int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
       for (int q = 0; q < 6; ++q) { markf(E); memcpy(&wf[offf.back()], six[q], E * 4); }
     }
     HIPCHK(ctx, ctx->enc16.alloc(w16.size() * 2));
+    HIPCHK(ctx, ctx->encd16.alloc(d16.size() * 2));
     HIPCHK(ctx, ctx->encf32.alloc(wf.size() * 4));
     HIPCHK(ctx, hipMemcpy(ctx->enc16.p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->encd16.p, d16.data(), d16.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->encf32.p, wf.data(), wf.size() * 4, hipMemcpyHostToDevice));
-    const uint16_t* d16 = ctx->enc16.as<uint16_t>();
+    const uint16_t* e16 = ctx->enc16.as<uint16_t>();
     const float* df = ctx->encf32.as<float>();
     EncWeights& w = ctx->encw;
     size_t i16 = 0, iff = 0;
-    w.w_patch = d16 + off16[i16++];
+    w.w_patch = e16 + off16[i16++];
     w.b_patch = df + offf[iff++];
     w.pos = df + offf[iff++];
     w.lnf_s = df + offf[iff++];
     w.lnf_b = df + offf[iff++];
     for (int i = 0; i < g.enc_layers; ++i) {
       EncLayerW& L = w.layer[i];
-      L.wqkv = d16 + off16[i16++]; L.wo = d16 + off16[i16++]; L.w1 = d16 + off16[i16++]; L.w2 = d16 + off16[i16++];
+      const uint16_t* dd = ctx->encd16.as<uint16_t>();
+      L.dqkv = dd + off16[i16]; L.wqkv = e16 + off16[i16++]; L.dwo = dd + off16[i16]; L.wo = e16 + off16[i16++];
+      L.dw1 = dd + off16[i16]; L.w1 = e16 + off16[i16++]; L.dw2 = dd + off16[i16]; L.w2 = e16 + off16[i16++];
       L.bqkv = df + offf[iff++]; L.bo = df + offf[iff++]; L.b1 = df + offf[iff++]; L.b2 = df + offf[iff++];
       L.ln1_s = df + offf[iff++]; L.ln1_b = df + offf[iff++]; L.ln2_s = df + offf[iff++]; L.ln2_b = df + offf[iff++];
       L.ls1 = df + offf[iff++]; L.ls2 = df + offf[iff++];
@@ -478,7 +497,8 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
   const Geom& g = ctx->g;
   const size_t S = g.S(), E = g.E, F = g.enc_mlp, rows = (size_t)b0 * S;
   EncWorkspace ws{ctx->ws_x.as<float>() + rows * E, static_cast<char*>(ctx->ws_h.p) + rows * E * 2,
-                  static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + rows * F * 2};
+                  static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + rows * F * 2,
+                  ctx->ws_parts.as<float>() + (size_t)b0 * parts_per_image(g), ctx->ws_corr.as<float>() + (size_t)b0 * (F > 3 * E ? F : 3 * E)};
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
                              &ctx->prof, keep_cls));
@@ -499,6 +519,31 @@ int hvla_encode_hidden(hvla_ctx* ctx, const uint8_t* images, float* hidden, int3
   if (!images || !hidden) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return encode_range(ctx, images, hidden, 0, B, true, reinterpret_cast<hipStream_t>(stream));
+}
+
+// test instrumentation: the encoder with a range audit of every 16-bit MFMA operand it writes (LayerNorm outputs, q / k /
+// v, attention outputs, GELU outputs; all layers).  maxabs f32 [4], nonfinite i32 [4]: HOST pointers.
+int hvla_encode_audit(hvla_ctx* ctx, const uint8_t* images, int32_t B, float* maxabs, int32_t* nonfinite, void* stream) {
+  if (!ctx) return HVLA_E_STATE;
+  if (int r = check_step(ctx, B)) return r;
+  if (!images || !maxabs || !nonfinite) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  uint32_t* slots = reinterpret_cast<uint32_t*>(ctx->flags.p);
+  HIPCHK(ctx, hipMemsetAsync(slots, 0, 8 * sizeof(uint32_t), st));
+  const Geom& g = ctx->g;
+  const size_t F = g.enc_mlp, E = g.E;
+  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p, ctx->ws_parts.as<float>(), ctx->ws_corr.as<float>()};
+  (void)F; (void)E;
+  HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images, ctx->tokens.as<float>(), B, st, nullptr, false, slots));
+  uint32_t h[8];
+  HIPCHK(ctx, hipMemcpyAsync(h, slots, sizeof h, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  for (int i = 0; i < 4; ++i) {
+    memcpy(&maxabs[i], &h[2 * i], 4);
+    nonfinite[i] = (int32_t)h[2 * i + 1];
+  }
+  return HVLA_OK;
 }
 
 static int policy_range(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float* actions, float* logits, int b0,

@@ -40,6 +40,7 @@ hipError_t launch_export_theta(const __bf16* wh, const __bf16* wl, const float* 
 // ---------------------------------------------------------------- image encoder (DINOv2)
 struct EncLayerW {
   const void *wqkv, *wo, *w1, *w2;               // 16-bit [N][K] (K contiguous)
+  const void *dqkv, *dwo, *dw1, *dw2;            // 16-bit [N][K]: (W - the 16-bit W above) x 4096, the rounding the corr table compensates
   const float *bqkv, *bo, *b1, *b2;              // f32
   const float *ln1_s, *ln1_b, *ln2_s, *ln2_b, *ls1, *ls2;
 };
@@ -56,6 +57,8 @@ struct EncWorkspace {
   void* h;         // [B*S, E] 16-bit LN output / attention output
   void* qkv;       // [B*S, 3E] 16-bit
   void* g;         // [B*S, F] 16-bit MLP hidden; also holds the im2col matrix [B*P, Kp]
+  float* parts;    // [B, 2, max(E, F)] column sums of the current GEMM's activation operand over each image's patch rows
+  float* corr;     // [B, max(3E, F)] per-image bias row of the current GEMM (bias + mean row . dW)
 };
 // optional live timing: a pool of hipEvent pairs tagged with a category (include/hvla.h HVLA_PROF_*)
 struct Profiler {
@@ -63,7 +66,7 @@ struct Profiler {
   std::vector<hipEvent_t> start, stop;
   std::vector<int> cat;
   size_t used = 0;
-  bool want(int c) const { return mode == 2 || (mode == 1 && c == 5); }
+  bool want(int c) const { return c >= 0 && (mode == 2 || (mode == 1 && c == 5)); }
   void begin(int c, hipStream_t st) {
     if (!want(c)) return;
     if (used == start.size()) {
@@ -82,7 +85,8 @@ struct Profiler {
 };
 hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const EncWorkspace& ws,
                           const uint8_t* images, float* tokens, int B, hipStream_t st, Profiler* prof,
-                          bool keep_cls = false);   // keep_cls: tokens = f32 [B, S, E] last_hidden_state
+                          bool keep_cls = false,    // keep_cls: tokens = f32 [B, S, E] last_hidden_state
+                          uint32_t* audit = nullptr);   // [4 sites][2]: max |16-bit operand| (float bits), non-finite count
 
 hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st);

@@ -19,8 +19,9 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
-           "hvla_t5_encode", "hvla_preprocess"]
-PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy"]
+           "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit"]
+PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy",
+              "weight_rounding_compensation"]
 
 
 class hvla_config(C.Structure):
@@ -118,6 +119,8 @@ def load_library():
     lib.hvla_profile.restype = C.c_int
     lib.hvla_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
     lib.hvla_profile_read.restype = C.c_int
+    lib.hvla_encode_audit.argtypes = [vp, vp, i32, C.POINTER(C.c_float), C.POINTER(i32), vp]
+    lib.hvla_encode_audit.restype = C.c_int
     lib.hvla_selftest.argtypes = [vp, vp]
     lib.hvla_selftest.restype = C.c_int
     _lib = lib
@@ -195,6 +198,12 @@ class Context:
 
     def t5_encode(self, ids_ptr, mask_ptr, out_ptr, B, T, stream=0):
         self._check(self.lib.hvla_t5_encode(self.h, ids_ptr, mask_ptr, out_ptr, B, T, C.c_void_p(stream)), "hvla_t5_encode")
+
+    def encode_audit(self, images_ptr, B, stream: int = 0):
+        """{site: (largest finite |16-bit operand|, number of inf / NaN)} over all encoder layers (tests)."""
+        mx, bad = (C.c_float * 4)(), (C.c_int32 * 4)()
+        self._check(self.lib.hvla_encode_audit(self.h, C.c_void_p(images_ptr), B, mx, bad, C.c_void_p(stream)), "hvla_encode_audit")
+        return {k: (float(mx[i]), int(bad[i])) for i, k in enumerate(("layernorm_out", "qkv", "attention_out", "gelu_out"))}
 
     def selftest(self, stream: int = 0):
         self._check(self.lib.hvla_selftest(self.h, C.c_void_p(stream)), "hvla_selftest")

@@ -138,9 +138,9 @@ class HyperVLA:
                 json.dump(_tree_map(lambda x: np.asarray(x).tolist(), self.dataset_statistics), f)
 
     @classmethod
-    def from_synthetic(cls, geometry: Geometry = FULL, **kw) -> "HyperVLA":
+    def from_synthetic(cls, geometry: Geometry = FULL, params: Optional[Dict[str, np.ndarray]] = None, **kw) -> "HyperVLA":
         from . import synthetic
-        return cls(default_config(geometry), synthetic.synthetic_params(geometry), None,
+        return cls(default_config(geometry), synthetic.synthetic_params(geometry) if params is None else params, None,
                    synthetic.synthetic_dataset_statistics(geometry), **kw)
 
     def replace(self, **changes) -> "HyperVLA":

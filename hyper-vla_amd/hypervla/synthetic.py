@@ -110,6 +110,74 @@ def synthetic_params(g: Geometry = FULL, seed: int = SEED_WEIGHTS) -> Dict[str, 
     return p
 
 
+def synthetic_params_trained_like(g: Geometry = FULL, seed: int = SEED_WEIGHTS + 1) -> Dict[str, np.ndarray]:
+    """`synthetic_params` with the image encoder re-drawn to the statistics a *trained* DINOv2 shows and random-init
+    weights do not (no pretrained checkpoint exists offline): LayerScale in [0.05, 1] instead of 1.0, a few outlier
+    channels of magnitude >= 100 in the residual stream from the second layer on (the 'massive activations' of ViTs:
+    injected by fc2's bias plus token-dependent fc2 columns, and damped by small LayerNorm scales on those channels as
+    trained models do), heavy-tailed LayerNorm scales and fc1 columns (pre-activations up to a few tens), sharper
+    attention.  Used by the parity tests to check that 16-bit operands neither overflow nor lose the tolerance on such
+    weights; the hypernetwork half is unchanged."""
+    p = synthetic_params(g, SEED_WEIGHTS)
+    rng = _rng(seed)
+    E, F, nl = g.enc_dim, g.enc_mlp, g.enc_layers
+    outl = rng.choice(E, size=4, replace=False)                       # the outlier channels
+    sign = rng.choice([-1.0, 1.0], size=4)
+
+    def put(path, v):
+        p[shared_name(path)] = np.asarray(v, np.float32).reshape(-1)
+
+    def leaf(path, shape):
+        return p[shared_name(path)].reshape(shape).astype(np.float64)
+
+    for i in range(nl):
+        L = ("encoder", "layer", str(i))
+        lam1, lam2 = rng.uniform(0.05, 1.0, size=E), rng.uniform(0.05, 1.0, size=E)
+        put(L + ("layer_scale1", "lambda1"), lam1)
+        put(L + ("layer_scale2", "lambda1"), lam2)
+        for nm in ("norm1", "norm2"):
+            sc = np.exp(0.5 * rng.standard_normal(E))
+            sc[outl] = 0.05 * rng.uniform(0.5, 1.5, size=4)            # trained models damp the outlier channels
+            put(L + (nm, "scale"), sc)
+            put(L + (nm, "bias"), 0.1 * rng.standard_normal(E))
+        w1 = leaf(L + ("mlp", "fc1", "kernel"), (E, F)) * np.exp(0.8 * rng.standard_normal(F))[None, :]
+        put(L + ("mlp", "fc1", "kernel"), w1)
+        put(L + ("mlp", "fc1", "bias"), 0.5 * rng.standard_normal(F))
+        for nm, k in (("query", 2.0), ("key", 2.0)):
+            put(L + ("attention", "attention", nm, "kernel"), leaf(L + ("attention", "attention", nm, "kernel"), (E, E)) * k)
+        if i == 1:                                                     # the layer that creates the outliers
+            w2 = leaf(L + ("mlp", "fc2", "kernel"), (F, E))
+            b2 = leaf(L + ("mlp", "fc2", "bias"), (E,))
+            w2[:, outl] *= 30.0                                        # token-dependent part
+            b2[outl] = sign * 130.0 / lam2[outl]                       # constant part: |x| >= 100 afterwards
+            put(L + ("mlp", "fc2", "kernel"), w2)
+            put(L + ("mlp", "fc2", "bias"), b2)
+    return p
+
+
+def synthetic_images_structured(batch: int, g: Geometry = FULL, rank: int = 0) -> np.ndarray:
+    """uint8 [B, 1, H, W, 3] observations that differ from image to image the way camera frames do and iid noise does
+    not: per-image brightness / contrast / colour cast, a smooth low-frequency scene (a few random blobs and a
+    gradient) and mild sensor noise.  Parity tests use them next to `synthetic_images` so that per-image activation
+    statistics are not all alike."""
+    rng = _rng(SEED_IMAGES + 500 + rank)
+    S = g.image_size
+    yy, xx = np.meshgrid(np.linspace(-1, 1, S), np.linspace(-1, 1, S), indexing="ij")
+    out = np.empty((batch, 1, S, S, 3), np.uint8)
+    for b in range(batch):
+        img = np.zeros((S, S, 3))
+        gx, gy = rng.normal(0, 0.4, size=2)
+        img += (gx * xx + gy * yy)[..., None]
+        for _ in range(int(rng.integers(3, 9))):
+            cx, cy, r = rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.1, 0.6)
+            col = rng.normal(0, 0.6, size=3)
+            img += np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r))[..., None] * col
+        img = img * rng.uniform(0.3, 1.2) + rng.uniform(-0.5, 0.5) + rng.normal(0, 0.15, size=3)
+        img += rng.normal(0, rng.uniform(0.01, 0.08), size=img.shape)
+        out[b, 0] = np.clip(np.rint(127.5 + 100.0 * img), 0, 255).astype(np.uint8)
+    return out
+
+
 def synthetic_images(batch: int, g: Geometry = FULL, rank: int = 0) -> np.ndarray:
     """uint8 [B, 1, H, W, 3] observations (OXE ``image_primary`` with window 1)."""
     rng = _rng(SEED_IMAGES + rank)

@@ -219,9 +219,15 @@ int hvla_t5_encode(hvla_ctx* ctx, const int64_t* input_ids, const int64_t* atten
 #define HVLA_PROF_FC1 5     /* encoder fc1 GEMM (+erf GELU)             */
 #define HVLA_PROF_FC2 6     /* encoder fc2 GEMM (+residual)             */
 #define HVLA_PROF_POLICY 7  /* generated-policy megakernel              */
-#define HVLA_PROF_N 8
+#define HVLA_PROF_COMP 8    /* encoder: column sums + per-image bias rows that compensate the weight rounding */
+#define HVLA_PROF_N 9
 int hvla_profile(hvla_ctx* ctx, int32_t mode);
 int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches);
+
+/* Test instrumentation: hvla_encode with a range audit of every 16-bit MFMA operand the encoder writes, over all layers:
+ * site 0 LayerNorm outputs, 1 stored q / k / v, 2 attention outputs, 3 GELU outputs.  maxabs f32 [4] = largest finite
+ * |value| per site, nonfinite i32 [4] = number of inf / NaN values (an fp16 overflow shows up here).  HOST pointers.    */
+int hvla_encode_audit(hvla_ctx* ctx, const uint8_t* images, int32_t B, float* maxabs, int32_t* nonfinite, void* stream);
 
 /* Primitive self-check used by tests: runs the MFMA fragment-layout probes on the ctx's device
  * and returns HVLA_OK only if every probe matches its exact integer expectation.                */

@@ -11,8 +11,18 @@ regenerated from the fixed seeds.  Files:
   full_b4.npz     README geometry (DINOv2-base, vit_t), B=4: ctx, generated-parameter checksum and
                   64 sampled entries per leaf, sampled encoder tokens, action-token embedding,
                   gripper logits, actions
+  full_b64*.npz   README geometry, 64 episodes (the sample the end-to-end tolerance is asserted on): actions, gripper
+                  logits, action-token embedding, 256 sampled tokens per episode, for
+                    full_b64.npz             synthetic weights, iid-noise images
+                    full_b64_trained.npz     trained-DINOv2-like encoder statistics (LayerScale 0.05..1, outlier channels
+                                             >= 100 in the residual stream, heavy-tailed fc1), iid-noise images
+                    full_b64_structured.npz  synthetic weights, camera-like images (smooth scenes, per-image brightness /
+                                             contrast): neighbouring tokens are similar, so rounding errors are correlated
   wrapper.npz     caller-side chain (un-normalise, ensemble, axis-angle, gripper rules) for the three
                   policy setups on a seeded raw-action sequence
+
+    python tests/golden/make_golden.py            # everything (about ten minutes on 8 cores)
+    python tests/golden/make_golden.py b64        # only the three 64-episode fixtures
 """
 import os
 import sys
@@ -30,17 +40,45 @@ from oracle import hvla_ref_np as onp                               # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
-def run(g, B, sink=None):
-    P = syn.synthetic_params(g)
+def run(g, B, sink=None, params=None, images=None):
+    P = syn.synthetic_params(g) if params is None else params
     leaves, enc_shapes = generated_leaves(g), dict(encoder_leaves(g))
-    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    ins, st = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g)
+    im = syn.synthetic_images(B, g) if images is None else images
     bp, ctx = onp.create_tasks(P, g, leaves, ins, st, sink)
     act, logit, emb, tok = onp.sample_actions(P, g, enc_shapes, bp, im, sink)
     theta = np.concatenate([bp[l.flat_name].reshape(B, -1) for l in leaves], 1)
     return dict(ctx=ctx[:, 0], theta=theta, actions=act, logits=logit, emb=emb, tokens=tok)
 
 
+def b64():
+    """The three 64-episode fixtures at the README geometry (in chunks of 16 episodes: the float64 encoder needs about
+    1 GB per 16 images)."""
+    B, CH = 64, 16
+    cases = {"full_b64.npz": (None, syn.synthetic_images(B, FULL)),
+             "full_b64_trained.npz": (syn.synthetic_params_trained_like(FULL), syn.synthetic_images(B, FULL)),
+             "full_b64_structured.npz": (None, syn.synthetic_images_structured(B, FULL))}
+    rng = np.random.Generator(np.random.PCG64(79))
+    tok_idx = np.sort(rng.choice(FULL.patches * FULL.enc_dim, size=256, replace=False))
+    leaves, enc_shapes = generated_leaves(FULL), dict(encoder_leaves(FULL))
+    for name, (params, images) in cases.items():
+        P = syn.synthetic_params(FULL) if params is None else params
+        ins, st = syn.synthetic_instructions(B, FULL), syn.synthetic_initial_state(B, FULL)
+        bp, ctx = onp.create_tasks(P, FULL, leaves, ins, st)
+        acts, logits, embs, toks = [], [], [], []
+        for c in range(0, B, CH):
+            sub = {k: v[c:c + CH] for k, v in bp.items()}
+            a, l, e, t = onp.sample_actions(P, FULL, enc_shapes, sub, images[c:c + CH])
+            acts.append(a), logits.append(l), embs.append(e), toks.append(t.reshape(CH, -1)[:, tok_idx])
+        np.savez_compressed(os.path.join(OUT, name), actions=np.concatenate(acts), logits=np.concatenate(logits),
+                            emb=np.concatenate(embs), tok_idx=tok_idx, tok_samples=np.concatenate(toks))
+        print(name, os.path.getsize(os.path.join(OUT, name)), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "b64":
+        return b64()
+    b64()
     # ---- tiny: everything
     sink = {}
     r = run(TINY, 3, sink)
