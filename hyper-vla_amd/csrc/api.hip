@@ -54,9 +54,9 @@ inline uint16_t f2h(float f) {
 }  // namespace
 
 // floats of column-sum scratch per image: two halves of the widest activation row (GELU outputs), or one partial per
-// 32-row chunk of a LayerNorm output
+// 16-row chunk of a LayerNorm output
 static size_t parts_per_image(const Geom& g) {
-  const size_t a = (size_t)2 * (g.enc_mlp > g.E ? g.enc_mlp : g.E), b = (size_t)((g.S() + 31) / 32) * g.E;
+  const size_t a = (size_t)2 * (g.enc_mlp > g.E ? g.enc_mlp : g.E), b = (size_t)((g.S() + 15) / 16) * g.E;
   return a > b ? a : b;
 }
 
@@ -80,7 +80,7 @@ struct hvla_ctx {
   DevBuf enc16, encd16, encf32;  // encoder matrices (16-bit), their rounding residues x 4096 (16-bit) and vectors (f32)
   EncWeights encw{};
   // workspaces (sized for cfg.max_batch)
-  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_parts, ws_corr, tokens, flags;
+  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_parts, ws_corr, ws_abar, tokens, flags;
   Profiler prof;
   // cfg.streams == 2: helper stream and fork / join events of hvla_step
   hipStream_t side = nullptr;
@@ -132,7 +132,8 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   Geom& g = ctx->g;
   g = Geom{c->image_size, c->patch, c->enc_dim, c->enc_layers, c->enc_heads, c->enc_mlp,
            c->dim, c->layers, c->heads, c->mlp, c->horizon, c->action_dim, c->tanh_scale, c->max_action,
-           c->ctx_dim, c->ctx_layers, c->ctx_heads, c->ctx_mlp, c->lang_tokens, c->lang_dim, c->scale_context};
+           c->ctx_dim, c->ctx_layers, c->ctx_heads, c->ctx_mlp, c->lang_tokens, c->lang_dim, c->scale_context,
+           c->clip_target != 0};
   // what the hand-written kernels are specialised for (anything else is refused, never emulated)
   const int P = g.P();
   const bool ok = c->dim == 64 && c->heads == 4 && c->mlp % 32 == 0 && c->mlp >= 32 && c->enc_dim % 128 == 0 &&
@@ -166,6 +167,7 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   A(ctx->ws_x, Bm * S * E * 4); A(ctx->ws_h, Bm * S * E * 2); A(ctx->ws_qkv, Bm * S * 3 * E * 2);
   A(ctx->ws_g, gbytes); A(ctx->tokens, Bm * P * E * 4); A(ctx->flags, 64 * sizeof(int));
   A(ctx->ws_parts, Bm * parts_per_image(g) * 4); A(ctx->ws_corr, Bm * (F > 3 * E ? F : 3 * E) * 4);
+  A(ctx->ws_abar, Bm * (F > E ? F : E) * 2);
   if (e != hipSuccess) return HVLA_E_ARENA_FULL;
   if (c->streams == 2) {
     if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
@@ -498,7 +500,8 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
   const size_t S = g.S(), E = g.E, F = g.enc_mlp, rows = (size_t)b0 * S;
   EncWorkspace ws{ctx->ws_x.as<float>() + rows * E, static_cast<char*>(ctx->ws_h.p) + rows * E * 2,
                   static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + rows * F * 2,
-                  ctx->ws_parts.as<float>() + (size_t)b0 * parts_per_image(g), ctx->ws_corr.as<float>() + (size_t)b0 * (F > 3 * E ? F : 3 * E)};
+                  ctx->ws_parts.as<float>() + (size_t)b0 * parts_per_image(g), ctx->ws_corr.as<float>() + (size_t)b0 * (F > 3 * E ? F : 3 * E),
+                  static_cast<char*>(ctx->ws_abar.p) + (size_t)b0 * (F > E ? F : E) * 2};
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
                              &ctx->prof, keep_cls));
@@ -533,7 +536,7 @@ int hvla_encode_audit(hvla_ctx* ctx, const uint8_t* images, int32_t B, float* ma
   HIPCHK(ctx, hipMemsetAsync(slots, 0, 8 * sizeof(uint32_t), st));
   const Geom& g = ctx->g;
   const size_t F = g.enc_mlp, E = g.E;
-  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p, ctx->ws_parts.as<float>(), ctx->ws_corr.as<float>()};
+  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p, ctx->ws_parts.as<float>(), ctx->ws_corr.as<float>(), ctx->ws_abar.p};
   (void)F; (void)E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images, ctx->tokens.as<float>(), B, st, nullptr, false, slots));
   uint32_t h[8];
@@ -621,7 +624,7 @@ int hvla_loss(hvla_ctx* ctx, const float* actions, const float* logits, const fl
   if (!actions || !logits || !target || !tmask || !amask || !loss) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, launch_loss(actions, logits, target, tmask, amask, loss, B, ctx->g.horizon, ctx->g.action_dim,
-                          ctx->g.max_action, reinterpret_cast<hipStream_t>(stream)));
+                          ctx->g.max_action, ctx->g.clip_target != 0, reinterpret_cast<hipStream_t>(stream)));
   return HVLA_OK;
 }
 
@@ -669,6 +672,16 @@ int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_tr
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const TrainLayout L = make_train_layout(ctx->g);
   HIPCHK(ctx, train_apply(L, to_tb(buf), to_hp(hy), hy->train_encoder != 0, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
+
+int hvla_train_accumulate(hvla_ctx* ctx, const hvla_train_buffers* buf, float* acc, float inv_k, const hvla_train_hyper* hy,
+                          void* stream) {
+  if (!ctx || !buf || !hy) return HVLA_E_STATE;
+  if (!buf->grads || !buf->sqsum || !acc) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const TrainLayout L = make_train_layout(ctx->g);
+  HIPCHK(ctx, train_accumulate(L, to_tb(buf), acc, inv_k, to_hp(hy), hy->train_encoder != 0, reinterpret_cast<hipStream_t>(stream)));
   return HVLA_OK;
 }
 

@@ -95,7 +95,7 @@ struct GemmArgs {
   // gemm256p_kernel: tile row t covers global rows tile_row0 + t * tile_stride .. + 255 (image-aligned: 1, S; the patch
   // GEMM's contiguous rows: 0, 256); nbm tile rows, every tile full
   int tile_row0 = 0, tile_stride = 256, nbm = 0;
-  float* colsum = nullptr;       // GELU, image-aligned tiles only: [B][2][N] column sums of the rounded outputs of a tile
+  void* colmean = nullptr;       // GELU, image-aligned tiles only: [B][N] 16-bit mean over the tile's 256 rows of its rounded outputs
 };
 
 // Row-major epilogue shared by the three GEMM kernels.  They run the MFMA with the activation fragment as the first
@@ -111,11 +111,13 @@ __device__ __forceinline__ int wperm(int rho) { return (rho & ~63) + 4 * (rho & 
 // corr table); otherwise one bias row per call (pre_b4, or g.bias).  FULL: every row of the wave tile exists -- straight-
 // line code with 32-bit element offsets (with per-row `m < M` branches the compiler puts an s_waitcnt vmcnt(0) into every
 // predicated block, which also waits for the previous STORE: 32 serialised store round trips per wave, 6.5 us per tile).
-// CS (GELU, FULL only): also returns in cs[c] this lane's sum over its rows of the ROUNDED outputs of column c.
+// CS (GELU, FULL only): also returns in cs this lane's sums over its rows of the ROUNDED outputs of its four columns,
+// accumulated in the operand type itself (fp16: two v_pk_add_f16 per row instead of four converts and four adds; 32 values
+// per lane, and the mean row only needs a few per cent: colsum_kernel restates exactly this arithmetic).
 template <typename Op, int EPI, int MT, bool FULL, bool ROWBIAS, bool CS = false>
 __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
                                                         int fr, int fq, const f32x4* pre_b4, const f32x4* pre_l4,
-                                                        float* cs = nullptr) {
+                                                        typename Op::x4* cs = nullptr) {
   using T = typename Op::elem;
   const int n = n_base + 4 * fr;
   f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -171,10 +173,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
           typename Op::x4 o;
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = (T)t[c][r];
-          if constexpr (CS) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) cs[c] += (float)o[c];     // rows in ascending order: the order colsum_kernel restates
-          }
+          if constexpr (CS) *cs += o;                      // rows in ascending order: the order colsum_kernel restates
           *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]) = o;
         } else if constexpr (EPI == EPI_RES) {
           f32x4 x = xin[u][r];
@@ -591,18 +590,32 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       }
     }
     if constexpr (EPI == EPI_GELU) {
-      if (g.colsum) {
-        // column sums of this tile's rounded outputs for the fc2 compensation: lane sums its 32 rows (ascending), the four
-        // lanes that share the columns combine as (fq0 + fq1) + (fq2 + fq3), each wave row writes its own half
-        float cs[4] = {0.f, 0.f, 0.f, 0.f};
-        gemm_epilogue_rows_impl<Op, EPI, 8, true, false, true>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4, cs);
+      if (g.colmean) {
+        // mean row of this tile's rounded outputs for the fc2 compensation: lane sums its 32 rows (ascending, in the
+        // operand type), the four lanes that share the columns combine in f32 as (fq0 + fq1) + (fq2 + fq3), the two wave
+        // rows as half0 + half1 through LDS (the W half of buffer 1: not part of the next tile's prologue DMA)
+        typename Op::x4 csh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) csh[c] = (T)0.f;
+        gemm_epilogue_rows_impl<Op, EPI, 8, true, false, true>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4, &csh);
+        f32x4 cs;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+          cs[c] = (float)csh[c];
           cs[c] += __shfl_xor(cs[c], 16, 64);
           cs[c] += __shfl_xor(cs[c], 32, 64);
         }
-        if (fq == 0)
-          *reinterpret_cast<f32x4*>(g.colsum + ((size_t)ctm * 2 + wm) * g.N + cn0 + wn * 64 + 4 * fr) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+        f32x4* xch = reinterpret_cast<f32x4*>(smem + 65536 + 32768) + wn * 16 + fr;
+        if (wm == 1 && fq == 0) *xch = cs;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HVLA_BAR();
+        if (wm == 0 && fq == 0) {
+          const f32x4 tot = cs + *xch;
+          typename Op::x4 mo;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) mo[c] = (T)(tot[c] * (1.f / 256.f));
+          *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.colmean) + (size_t)ctm * g.N + cn0 + wn * 64 + 4 * fr) = mo;
+        }
       } else {
         gemm_epilogue_rows_impl<Op, EPI, 8, true, false>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
       }
@@ -685,45 +698,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // LayerNorm in front of a GEMM (norm1 / norm2), with the column sums of its output that the GEMM's weight-rounding
-// compensation needs (corr_kernel): workgroup (c, b) = rows [32 c, 32 c + 32) of image b, wave w takes rows 4 w .. 4 w + 3
-// of them (all loads first), each lane keeps the running sums of its columns, the eight waves are combined through LDS in
-// wave order: parts[b][c][E].  Chunks are relative to the image, so the sums do not depend on where the image sits in the
+// compensation needs (corr_kernel): workgroup (c, b) = rows [16 c, 16 c + 16) of image b, wave w takes rows 4 w .. 4 w + 3
+// of them one after the other (the next row's loads in flight), each lane keeps the running sums of its columns, the four
+// waves are combined through LDS in wave order: parts[b][c][E].  Chunks are relative to the image, so the sums do not depend on where the image sits in the
 // batch.  E % 4 == 0, E <= 1024.
 template <typename Op>
-__global__ __launch_bounds__(512) void layernorm_cs_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
+__global__ __launch_bounds__(256) void layernorm_cs_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
                                                            const float* __restrict__ scale, const float* __restrict__ bias,
                                                            float* __restrict__ parts, int S, int E) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [8][E / 4]
+  f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [4][E / 4]
   const int b = blockIdx.y, c = blockIdx.x, nchunk = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n4 = E / 4;
-  const int r0 = 32 * c + 4 * wave;
-  f32x4 v[4][4], cs[4], s4[4], b4[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int col = lane + 64 * i;
-    cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s4[i] = col < n4 ? reinterpret_cast<const f32x4*>(scale)[col] : f32x4{0.f, 0.f, 0.f, 0.f};
-    b4[i] = col < n4 ? reinterpret_cast<const f32x4*>(bias)[col] : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = r0 + rr;
+  const int r0 = 16 * c + 4 * wave;                                  // this wave's rows r0 .. r0 + 3 of the image
+  f32x4 cs[4], cur[4], nxt[4];
+  auto load = [&](f32x4 (&v)[4], int row) {
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((size_t)b * S + (row < S ? row : S - 1)) * E);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int col = lane + 64 * i;
-      v[rr][i] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[i] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  }
+  };
 #pragma unroll
+  for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load(cur, r0);
   for (int rr = 0; rr < 4; ++rr) {
     const int row = r0 + rr;
     if (row >= S) break;                                             // wave-uniform
+    if (rr + 1 < 4) load(nxt, row + 1);                              // the next row is in flight under this row's arithmetic
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sum += v[rr][i][0] + v[rr][i][1] + v[rr][i][2] + v[rr][i][3];
+    for (int i = 0; i < 4; ++i) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float mean = sum / E;
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(512) void layernorm_cs_kernel(const float* __restri
       if (lane + 64 * i < n4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float d = v[rr][i][j] - mean;
+          const float d = cur[i][j] - mean;
           sq += d * d;
         }
       }
@@ -746,17 +753,20 @@ __global__ __launch_bounds__(512) void layernorm_cs_kernel(const float* __restri
     for (int i = 0; i < 4; ++i) {
       const int col = lane + 64 * i;
       if (col < n4) {
+        const f32x4 s4 = reinterpret_cast<const f32x4*>(scale)[col], b4 = reinterpret_cast<const f32x4*>(bias)[col];
         f32x4 y;
         typename Op::x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          y[j] = (v[rr][i][j] - mean) * rstd * s4[i][j] + b4[i][j];
+          y[j] = (cur[i][j] - mean) * rstd * s4[j] + b4[j];
           o[j] = (typename Op::elem)y[j];
         }
         cs[i] += y;
         reinterpret_cast<typename Op::x4*>(orow)[col] = o;
       }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(512) void layernorm_cs_kernel(const float* __restri
   if ((int)threadIdx.x < n4) {
     f32x4 t = red[threadIdx.x];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) t += red[w * n4 + threadIdx.x];
+    for (int w = 1; w < 4; ++w) t += red[w * n4 + threadIdx.x];
     reinterpret_cast<f32x4*>(parts + ((size_t)b * nchunk + c) * E)[threadIdx.x] = t;
   }
 }
@@ -809,11 +819,11 @@ __device__ __forceinline__ float lane_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-// osum (nullable): [B][E] column sums of the output over all S tokens of the image, for the out-projection's weight-
-// rounding compensation (corr_kernel): the workgroup owns every row of its 64 columns.
+// omean (nullable): [B][E] 16-bit mean over all S tokens of the image of the output, the operand of the out-projection's
+// weight-rounding compensation (corr_kernel): the workgroup owns every row of its 64 columns.
 template <typename Op>
 __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, typename Op::elem* __restrict__ o,
-                                 int S, int E, int H, float* __restrict__ osum) {
+                                 int S, int E, int H, typename Op::elem* __restrict__ omean) {
   // S = 32 * NW + 1 tokens.  NW waves of 64 lanes: wave w owns queries [32 w, 32 w + 32) on the matrix cores;
   // the one remaining query (the last token) is done co-operatively on the VALU, wave w taking key tile w,
   // and combined through LDS.  8 waves per workgroup at S = 257 (2 per SIMD) so that two workgroups share a
@@ -961,7 +971,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         for (int r = 0; r < 4; ++r) {
           const float ov = O[mt][g4 * 4 + r] * inv;
           v4[r] = (T)ov;
-          if (osum) {                                      // sum over this half's 32 queries: 16-lane rows by DPP, then the two rows
+          if (omean) {                                     // sum over this half's 32 queries: 16-lane rows by DPP, then the two rows
             float t = row16_sum(ov);
             t += __shfl_xor(t, 16, 64);
             if ((lane & 31) == 0) csum[wave * 64 + mt * 32 + g4 * 8 + half * 4 + r] = t;
@@ -1027,10 +1037,10 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     }
     const float last = od / L;
     o[((size_t)b * S + (S - 1)) * E + head * 64 + lane] = (T)last;
-    if (osum) {
+    if (omean) {
       float t = csum[lane];
       for (int w = 1; w < NW; ++w) t += csum[w * 64 + lane];
-      osum[(size_t)b * E + head * 64 + lane] = t + last;
+      omean[(size_t)b * E + head * 64 + lane] = (T)((t + last) / (float)S);
     }
   }
 }
@@ -1044,7 +1054,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 // the table only needs the mean to a few per cent), as two halves so that gemm256p_kernel's GELU epilogue can produce the
 // same numbers for its own outputs (same values, same order of additions => same bits; the batch-invariance tests cross
 // the two): half wm = rows [wm P/2, +P/2) of the image; inside a half, quad q (rows 4q..4q+3) goes to partial q & 3, each
-// partial adds its values in ascending row order, and the half is (p0 + p1) + (p2 + p3).
+// partial adds its values in ascending row order IN THE 16-BIT TYPE, and the half is (p0 + p1) + (p2 + p3) in f32.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, float* __restrict__ parts, int S, int P, int K) {
   const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
@@ -1052,66 +1062,99 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, fl
   const T* base = a + ((size_t)b * S + 1) * K + n;
   const int half = P / 2;
   for (int wm = 0; wm < 2; ++wm) {
-    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    T p[4] = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};       // accumulated in the operand type, as the GELU epilogue does
     for (int q = 0; q < half / 4; ++q) {
-      float v[4];
+      T v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (float)base[(size_t)(wm * half + 4 * q + r) * K];
+      for (int r = 0; r < 4; ++r) v[r] = base[(size_t)(wm * half + 4 * q + r) * K];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[q & 3] += v[r];
+      for (int r = 0; r < 4; ++r) p[q & 3] = p[q & 3] + v[r];
     }
-    parts[((size_t)b * 2 + wm) * K + n] = (p[0] + p[1]) + (p[2] + p[3]);
+    parts[((size_t)b * 2 + wm) * K + n] = ((float)p[0] + (float)p[1]) + ((float)p[2] + (float)p[3]);
   }
 }
 
-// corr_kernel: corr[b][n] = bias[n] + (sum over parts of parts[b][.][k]) * inv . dW[n][k] / 4096, on the matrix cores
-// (16x16x32; rows = 16 images, columns = 64 outputs per workgroup; the four waves split K and are combined through LDS in
-// wave order).  dW is stored x4096 so that it stays in the normal range of fp16.  The mean row only needs a few bits (it
-// multiplies a 2^-12 relative quantity), so 16-bit operands are ample here.
-template <typename Op>
-__global__ __launch_bounds__(256) void corr_kernel(const float* __restrict__ parts, int nparts, float inv,
-                                                   const typename Op::elem* __restrict__ dW, const float* __restrict__ bias,
-                                                   float* __restrict__ corr, int B, int N, int K) {
+// mean16_kernel: the mean row of every image as a 16-bit MFMA operand, abar[b][k] = inv * (parts[b][0][k] + ... ), parts
+// added in ascending order.
+template <typename T>
+__global__ __launch_bounds__(256) void mean16_kernel(const float* __restrict__ parts, int nparts, float inv, T* __restrict__ abar, int K) {
+  const int b = blockIdx.y, k4 = blockIdx.x * 256 + threadIdx.x;
+  if (k4 * 4 >= K) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(parts + (size_t)b * nparts * K) + k4;
+  f32x4 s = p[0];
+  for (int q = 1; q < nparts; ++q) s += p[(size_t)q * (K / 4)];
+  typedef T x4 __attribute__((ext_vector_type(4)));
+  x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (T)(s[j] * inv);
+  reinterpret_cast<x4*>(abar + (size_t)b * K)[k4] = o;
+}
+
+// corr_kernel: corr[b][n] = bias[n] + abar[b][:] . dW[n][:] / 4096 on the matrix cores (16x16x32).  A workgroup owns 32
+// images x 64 columns; its NWV waves split K, every wave keeps the loads of UN k-steps in flight (the kernel is pure
+// latency: K = 768 is one round), and the partial tiles are added through LDS in wave order.  dW is stored x4096 so that
+// it stays in the normal range of fp16.  The mean row only needs a few bits (it multiplies a 2^-12 relative quantity), so
+// 16-bit operands are ample here.
+template <typename Op, int NWV>
+__global__ __launch_bounds__(NWV * 64) void corr_kernel(const typename Op::elem* __restrict__ abar,
+                                                        const typename Op::elem* __restrict__ dW, const float* __restrict__ bias,
+                                                        float* __restrict__ corr, int B, int N, int K) {
   using T = typename Op::elem;
   using X8 = typename Op::x8;
-  __shared__ f32x4 red[4][4][64];
+  constexpr int UN = 3;
+  __shared__ f32x4 red[NWV][4][64];                  // [wave][n-tile][lane], one m-tile at a time
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
+  const int b0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
   const int row = lane & 15, kg = lane >> 4;
-  const int b = b0 + row < B ? b0 + row : B - 1;
-  f32x4 acc[4];
+  f32x4 acc[2][4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* pa = parts + (size_t)b * nparts * K + kg * 8;
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const T* pa[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int b = b0 + mt * 16 + row;
+    pa[mt] = abar + (size_t)(b < B ? b : B - 1) * K + kg * 8;
+  }
   const T* pw = dW + (size_t)(n0 + row) * K + kg * 8;
-  for (int ks = wave; ks < K / 32; ks += 4) {
-    f32x4 s0 = *reinterpret_cast<const f32x4*>(pa + ks * 32), s1 = *reinterpret_cast<const f32x4*>(pa + ks * 32 + 4);
-    for (int p = 1; p < nparts; ++p) {
-      s0 += *reinterpret_cast<const f32x4*>(pa + (size_t)p * K + ks * 32);
-      s1 += *reinterpret_cast<const f32x4*>(pa + (size_t)p * K + ks * 32 + 4);
+  const int nsteps = K / 32;
+  for (int k0 = wave * UN; k0 < nsteps; k0 += NWV * UN) {
+    X8 af[UN][2], wf[UN][4];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int ks = k0 + u < nsteps ? k0 + u : nsteps - 1;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) af[u][mt] = *reinterpret_cast<const X8*>(pa[mt] + ks * 32);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[u][nt] = *reinterpret_cast<const X8*>(pw + (size_t)nt * 16 * K + ks * 32);
     }
-    X8 af;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) af[j] = (T)(s0[j] * inv), af[4 + j] = (T)(s1[j] * inv);
+    for (int u = 0; u < UN; ++u) {
+      if (k0 + u >= nsteps) break;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const X8 wf = *reinterpret_cast<const X8*>(pw + (size_t)nt * 16 * K + ks * 32);
-      acc[nt] = Op::mma16(af, wf, acc[nt]);
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = Op::mma16(af[u][mt], wf[u][nt], acc[mt][nt]);
     }
   }
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) red[wave][nt][lane] = acc[nt];
-  __syncthreads();
-  if (wave == 0) {
+  for (int mt = 0; mt < 2; ++mt) {                    // one m-tile (16 images) per round through the exchange buffer
+    if (mt) __syncthreads();
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const f32x4 s = ((red[0][nt][lane] + red[1][nt][lane]) + red[2][nt][lane]) + red[3][nt][lane];
-      const int n = n0 + nt * 16 + row;              // accumulator: column = lane & 15, rows 4 (lane >> 4) + r
+    for (int nt = 0; nt < 4; ++nt) red[wave][nt][lane] = acc[mt][nt];
+    __syncthreads();
+    if (wave < 4) {                                   // wave nt finishes column tile nt
+      const int nt = wave;
+      f32x4 sum = red[0][nt][lane];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w) sum += red[w][nt][lane];
+      const int n = n0 + nt * 16 + row;               // accumulator: column = lane & 15, rows 4 (lane >> 4) + r
       const float bn = bias[n];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int bi = b0 + 4 * kg + r;
-        if (bi < B) corr[(size_t)bi * N + n] = fmaf(s[r], 1.f / 4096.f, bn);
+        const int bi = b0 + mt * 16 + 4 * kg + r;
+        if (bi < B) corr[(size_t)bi * N + n] = fmaf(sum[r], 1.f / 4096.f, bn);
       }
     }
   }
@@ -1190,14 +1233,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   const int ncu = di.ncu;
   constexpr int G64_MAXM = 2047;       // rows up to which a GEMM is cut into 64x64 tiles (pure latency below that)
   constexpr int CAT_COMP = 8;          // HVLA_PROF_COMP
-  const bool comp = w.layer[0].dqkv != nullptr && ws.parts && ws.corr;
+  const bool comp = w.layer[0].dqkv != nullptr && ws.parts && ws.corr && ws.abar;
   // ---- one GEMM of the encoder: activations [B*S rows][K] -> [B*S rows][N]
   //  * images of 256 patches, batch >= 8, N % 256 == 0: gemm256p_kernel over image-aligned tiles (tile row b = rows
   //    b*S + 1 .. b*S + 256 = the patch rows of image b) + gemm64_kernel over the B CLS rows (stride S);
   //  * otherwise gemm64_kernel (<= 2047 rows) or gemm_kernel (128x128 tiles) over all rows, bias row looked up per row.
   // Returns whether the image-aligned form ran (then a GELU epilogue has written its column sums itself).
   auto gemm = [&](auto epic, const void* A, const void* Wt, int N, int K, const float* bias, const float* aux, void* out,
-                  int qcols, const float* corr, int cat, float* colsum = nullptr) -> bool {
+                  int qcols, const float* corr, int cat, void* colmean = nullptr) -> bool {
     constexpr int EPI = decltype(epic)::value;
     GemmArgs a{A, Wt, M, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
     a.corr = corr;
@@ -1206,13 +1249,13 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     pf.begin(cat, st);
     if (aligned) {
       const int nbn = N / HBN_;
-      a.nbm = B; a.tile_row0 = 1; a.tile_stride = S; a.colsum = colsum;
+      a.nbm = B; a.tile_row0 = 1; a.tile_stride = S; a.colmean = colmean;
       if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), 131072, st, a);
       else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), 131072, st, a);
       const bool main_only = pf.mode == 1;             // "dominant kernel only": the bracket covers the 256x256 launch alone
       if (main_only) pf.end(cat, st);
       GemmArgs c = a;
-      c.M = B; c.row0 = 0; c.row_step = S; c.colsum = nullptr;
+      c.M = B; c.row0 = 0; c.row_step = S; c.colmean = nullptr;
       hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(((B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
       if (!main_only) pf.end(cat, st);
       return true;
@@ -1228,14 +1271,21 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   // (ws.parts holds `nparts` partial sums per image and column, whose total times `inv` is the mean row)
   auto corr_for = [&](const void* dW, const float* bias, int N, int K, int nparts, float inv) -> const float* {
     if (!comp) return nullptr;
-    hipLaunchKernelGGL((corr_kernel<Op>), dim3((B + 15) / 16, N / 64), dim3(256), 0, st, ws.parts, nparts, inv,
-                       reinterpret_cast<const T*>(dW), bias, ws.corr, B, N, K);
+    if (nparts > 0)
+      hipLaunchKernelGGL((mean16_kernel<T>), dim3((K / 4 + 255) / 256, B), dim3(256), 0, st, ws.parts, nparts, inv,
+                         reinterpret_cast<T*>(ws.abar), K);
+    if (K >= 2048)
+      hipLaunchKernelGGL((corr_kernel<Op, 16>), dim3((B + 31) / 32, N / 64), dim3(1024), 0, st, reinterpret_cast<const T*>(ws.abar),
+                         reinterpret_cast<const T*>(dW), bias, ws.corr, B, N, K);
+    else
+      hipLaunchKernelGGL((corr_kernel<Op, 8>), dim3((B + 31) / 32, N / 64), dim3(512), 0, st, reinterpret_cast<const T*>(ws.abar),
+                         reinterpret_cast<const T*>(dW), bias, ws.corr, B, N, K);
     return ws.corr;
   };
-  const int nchunk = (S + 31) / 32;
+  const int nchunk = (S + 15) / 16;
   auto layernorm = [&](const float* sc, const float* bi) {           // norm1 / norm2 (+ the column sums of the output)
     if (comp)
-      hipLaunchKernelGGL((layernorm_cs_kernel<Op>), dim3(nchunk, B), dim3(512), (size_t)8 * E * sizeof(float), st, ws.x,
+      hipLaunchKernelGGL((layernorm_cs_kernel<Op>), dim3(nchunk, B), dim3(256), (size_t)4 * E * sizeof(float), st, ws.x,
                          reinterpret_cast<T*>(ws.h), sc, bi, ws.parts, S, E);
     else
       hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, sc, bi, M, E, S);
@@ -1280,23 +1330,21 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   for (int l = 0; l < g.enc_layers; ++l) {
     const EncLayerW& L = w.layer[l];
     pf.begin(1, st);
-    hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, L.ln1_s,
-                       L.ln1_b, M, E, S);
+    layernorm(L.ln1_s, L.ln1_b);
     pf.end(1, st);
-    pf.begin(CAT_COMP, st);
-    colsum_of(ws.h, E);
-    const float* cq = corr_for(L.dqkv, L.bqkv, 3 * E, E);
-    pf.end(CAT_COMP, st);
     audit_of(ws.h, (size_t)M * E, 0);
+    pf.begin(CAT_COMP, st);
+    const float* cq = corr_for(L.dqkv, L.bqkv, 3 * E, E, nchunk, 1.f / (float)S);
+    pf.end(CAT_COMP, st);
     gemm(EQ{}, ws.h, L.wqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, cq, 2);
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
     pf.begin(3, st);
     hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
-                       reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? ws.parts : nullptr);
+                       reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr);
     pf.end(3, st);
     audit_of(ws.h, (size_t)M * E, 2);
     pf.begin(CAT_COMP, st);
-    const float* co = corr_for(L.dwo, L.bo, E, E, 1, 1.f / (float)S);
+    const float* co = corr_for(L.dwo, L.bo, E, E, 0, 0.f);                 // the attention kernel wrote the mean row itself
     pf.end(CAT_COMP, st);
     gemm(ER{}, ws.h, L.wo, E, E, L.bo, L.ls1, ws.x, 0, co, 4);
     pf.begin(1, st);
@@ -1306,11 +1354,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     pf.begin(CAT_COMP, st);
     const float* c1 = corr_for(L.dw1, L.b1, F, E, nchunk, 1.f / (float)S);
     pf.end(CAT_COMP, st);
-    const bool summed = gemm(EG{}, ws.h, L.w1, F, E, L.b1, nullptr, ws.g, 0, c1, 5, comp ? ws.parts : nullptr);
+    const bool summed = gemm(EG{}, ws.h, L.w1, F, E, L.b1, nullptr, ws.g, 0, c1, 5, comp ? ws.abar : nullptr);
     audit_of(ws.g, (size_t)M * F, 3);
     pf.begin(CAT_COMP, st);
     if (!summed) colsum_of(ws.g, F);
-    const float* c2 = corr_for(L.dw2, L.b2, E, F, 2, 1.f / (float)P);
+    const float* c2 = corr_for(L.dw2, L.b2, E, F, summed ? 0 : 2, 1.f / (float)P);   // aligned tiles: the epilogue wrote the mean row
     pf.end(CAT_COMP, st);
     gemm(ER{}, ws.g, L.w2, E, F, L.b2, L.ls2, ws.x, 0, c2, 6);
   }

@@ -59,6 +59,7 @@ struct EncWorkspace {
   void* g;         // [B*S, F] 16-bit MLP hidden; also holds the im2col matrix [B*P, Kp]
   float* parts;    // [B, 2, max(E, F)] column sums of the current GEMM's activation operand over each image's patch rows
   float* corr;     // [B, max(3E, F)] per-image bias row of the current GEMM (bias + mean row . dW)
+  void* abar;      // [B, max(E, F)] 16-bit mean row of the current GEMM's activation operand
 };
 // optional live timing: a pool of hipEvent pairs tagged with a category (include/hvla.h HVLA_PROF_*)
 struct Profiler {
@@ -119,7 +120,7 @@ hipError_t launch_ensemble(const float* actions, float* ring, int* count, const 
 
 hipError_t launch_loss(const float* actions, const float* logits, const float* target, const uint8_t* tmask,
                        const uint8_t* amask, float* loss, int B, int horizon, int action_dim, float max_action,
-                       hipStream_t st);
+                       bool clip_target, hipStream_t st);
 
 // ---------------------------------------------------------------- self test
 hipError_t launch_selftest(int* fail_flags, hipStream_t st);

@@ -28,6 +28,7 @@ struct Geom {
   int D, L, H, M, horizon, action_dim;
   float tanh_scale, max_action;
   int C, ctx_layers, ctx_heads, ctx_mlp, T, lang_dim, scale_context;
+  int clip_target = 1;       // MixActionHead.loss: clip the action target to +-max_action (action_heads.py:499-500)
   int grid() const { return image_size / patch; }
   int P() const { return grid() * grid(); }
   int S() const { return P() + 1; }

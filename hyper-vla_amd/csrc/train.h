@@ -50,8 +50,8 @@ struct TrainBuffers {        // all device memory, owned by the caller
   float* actions;            // [B, horizon, action_dim] or null
   float* logits;             // [B, horizon] or null
   float* sqsum;              // [1]
-  const uint8_t* wd_mask;    // [G] 1 where the generated leaf is a base-net kernel (weight_decay_strategy v5);
-                             //     followed by [enc_total] 1 on the shared "kernel" leaves when the encoder is trained
+  const uint8_t* wd_mask;    // [total (+ enc_total)] 1 where decoupled weight decay applies: built by the host from the
+                             //     selected weight_decay_strategy (hypervla/train.py), flat parameter order
   const float* params0;      // [enc_total] pretrained encoder weights for the delta decay (train.py:465-471) or null
 };
 struct TrainInputs {
@@ -72,5 +72,7 @@ struct TrainHyper {
 hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& tb, const TrainInputs& in, int B,
                       const TrainHyper& hp, hipStream_t st);
 hipError_t train_apply(const TrainLayout& L, const TrainBuffers& tb, const TrainHyper& hp, bool train_encoder, hipStream_t st);
+hipError_t train_accumulate(const TrainLayout& L, const TrainBuffers& tb, float* acc, float inv_k, const TrainHyper& hp,
+                            bool train_encoder, hipStream_t st);
 
 }  // namespace hvla

@@ -617,6 +617,7 @@ struct HeadP {
   float* loss; float* dxrow;                // [B][D]
   float* actions; float* logits;            // optional outputs
   int B, S, D, Hz, ad; float tanh_scale, max_action;
+  int clip_target;                          // action_heads.py:499-500
 };
 __global__ void head_loss_kernel(HeadP p) {
   const int b = blockIdx.x, lane = threadIdx.x;            // 64 lanes, D == 64
@@ -645,7 +646,7 @@ __global__ void head_loss_kernel(HeadP p) {
     if (lane < A) { h = lane / (p.ad - 1); a = lane % (p.ad - 1); } else { h = lane - A; a = p.ad - 1; }
     const long o = ((long)b * p.Hz + h) * p.ad + a;
     mk = (tm && p.amask[o]) ? 1.f : 0.f;
-    tgt = fminf(fmaxf(p.target[o], -p.max_action), p.max_action);
+    tgt = p.clip_target ? fminf(fmaxf(p.target[o], -p.max_action), p.max_action) : p.target[o];
     if (lane < A) {
       pred = tanhf(z / p.tanh_scale) * p.max_action;
       cs = (pred - tgt) * (pred - tgt) * mk; cm = mk;
@@ -761,10 +762,18 @@ __global__ void sqsum_kernel(const float* __restrict__ g, long n, float* __restr
   for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, s);
 }
-// clip-by-global-norm -> AdamW (mu stored bf16, optax mu_dtype) -> EMA; wd applied on [wd_lo, wd_hi)
+// MultiSteps micro-step (octo/utils/train_utils.py:420-426: chain(clip_by_global_norm, MultiSteps(adamw))): the clipped
+// gradient of this micro-batch goes into the running mean, acc += clip(g) / k
+__global__ void accumulate_kernel(float* __restrict__ acc, const float* __restrict__ g, long n, const float* __restrict__ sq,
+                                  float clip, float inv_k) {
+  const float norm = sqrtf(sq[0]);
+  const float sc = (norm < clip ? 1.f : clip / norm) * inv_k;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc[i] = fmaf(g[i], sc, acc[i]);
+}
+// clip-by-global-norm -> AdamW (mu stored bf16, optax mu_dtype) -> EMA; decoupled weight decay where wd_mask[i] != 0
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, __bf16* __restrict__ mu,
                              float* __restrict__ nu, float* __restrict__ ema, long n, const float* __restrict__ sq,
-                             float clip, float lr, float b1, float b2, float eps, float wd, long wcat, long bcat, long G,
+                             float clip, float lr, float b1, float b2, float eps, float wd,
                              const uint8_t* __restrict__ wd_mask, float bc1, float bc2, float ema_decay) {
   const float norm = sqrtf(sq[0]);
   const float sc = norm < clip ? 1.f : clip / norm;
@@ -775,10 +784,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     mu[i] = (__bf16)m;
     nu[i] = v;
     float upd = (m / bc1) / (sqrtf(v / bc2) + eps);
-    if (i >= wcat && wd_mask) {            // weight_decay_strategy v5: heads that generate base-net kernels
-      const long gidx = i >= bcat ? i - bcat : (i - wcat) % G;
-      if (wd_mask[gidx]) upd += wd * p[i];
-    }
+    if (wd_mask && wd_mask[i]) upd += wd * p[i];     // the host builds the mask of the selected weight_decay_strategy
     const float pn = p[i] - lr * upd;
     p[i] = pn;
     if (ema) ema[i] = ema_decay * ema[i] + (1.f - ema_decay) * pn;
@@ -786,8 +792,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 // optimizer group "shared" (train_utils.py:414-419 + scripts/train.py:465-471): AdamW at base_lr, decay base_wd on the
-// leaves named *kernel* (mask), and -- as the reference does for every shared leaf when base_wd > 0 -- the update
-// gets + base_lr * base_wd * p0 (the pull back towards the pretrained weights p0).
+// masked leaves (every image_encoder leaf under weight_decay_strategy v5, the *kernel* leaves under v1), and -- as the
+// reference does for every shared leaf when base_wd > 0 -- the update gets + base_lr * base_wd * p0 (the pull back towards
+// the pretrained weights p0).
 __global__ void adamw_shared_kernel(float* __restrict__ p, const float* __restrict__ g, __bf16* __restrict__ mu,
                                     float* __restrict__ nu, float* __restrict__ ema, long n, const float* __restrict__ sq,
                                     float clip, float lr, float b1, float b2, float eps, float wd,
@@ -1108,7 +1115,7 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   // =============================== head + loss (+ backward seed) ===============================
   (void)hipMemsetAsync(pdx, 0, (size_t)B * S * D * 4, st);
   HeadP hpp{px_fin, (long)S * D, TH, tb.dtheta, G, off.wc, off.bc, off.wd, off.bd, off.ns, off.nb, in.target, in.tmask, in.amask,
-            tb.loss, hp.forward_only ? nullptr : dxrow, tb.actions, tb.logits, B, S, D, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
+            tb.loss, hp.forward_only ? nullptr : dxrow, tb.actions, tb.logits, B, S, D, g.horizon, g.action_dim, g.tanh_scale, g.max_action, g.clip_target};
   KL(head_loss_kernel, dim3(B), dim3(64), hpp);
   if (hp.forward_only) return hipGetLastError();
   KL(add_strided_kernel, g1((long)B * D), dim3(256), pdx + (long)(S - 1) * D, (long)S * D, dxrow, (long)D, B);
@@ -1161,11 +1168,20 @@ hipError_t train_apply(const TrainLayout& L, const TrainBuffers& tb, const Train
   const float t = (float)(hp.step + 1);
   const float bc1 = 1.f - powf(hp.b1, t), bc2 = 1.f - powf(hp.b2, t);
   KL(adamw_kernel, dim3(2048), dim3(256), tb.params, tb.grads, tb.mu, tb.nu, hp.ema_decay > 0.f ? tb.ema : nullptr, L.total, tb.sqsum,
-     hp.clip, hp.lr, hp.b1, hp.b2, hp.eps, hp.weight_decay, L.wcat, L.bcat, L.G, tb.wd_mask, bc1, bc2, hp.ema_decay);
+     hp.clip, hp.lr, hp.b1, hp.b2, hp.eps, hp.weight_decay, tb.wd_mask, bc1, bc2, hp.ema_decay);
   if (train_encoder)
     KL(adamw_shared_kernel, dim3(2048), dim3(256), tb.params + L.total, tb.grads + L.total, tb.mu + L.total, tb.nu + L.total,
        hp.ema_decay > 0.f ? tb.ema + L.total : nullptr, L.enc_total, tb.sqsum, hp.clip, hp.base_lr, hp.b1, hp.b2, hp.eps,
-       hp.base_weight_decay, tb.wd_mask ? tb.wd_mask + L.G : nullptr, tb.params0, bc1, bc2, hp.ema_decay);
+       hp.base_weight_decay, tb.wd_mask ? tb.wd_mask + L.total : nullptr, tb.params0, bc1, bc2, hp.ema_decay);
+  return hipGetLastError();
+}
+
+hipError_t train_accumulate(const TrainLayout& L, const TrainBuffers& tb, float* acc, float inv_k, const TrainHyper& hp,
+                            bool train_encoder, hipStream_t st) {
+  const long n = L.total + (train_encoder ? L.enc_total : 0);
+  (void)hipMemsetAsync(tb.sqsum, 0, 4, st);
+  KL(sqsum_kernel, dim3(1024), dim3(256), tb.grads, n, tb.sqsum);
+  KL(accumulate_kernel, dim3(2048), dim3(256), acc, tb.grads, n, tb.sqsum, hp.clip, inv_k);
   return hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
-           "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit"]
+           "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit", "hvla_train_accumulate"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy",
               "weight_rounding_compensation"]
 
@@ -30,7 +30,7 @@ class hvla_config(C.Structure):
                                          "action_dim")] + \
                [("tanh_scale", C.c_float), ("max_action", C.c_float)] + \
                [(n, C.c_int32) for n in ("ctx_dim", "ctx_layers", "ctx_heads", "ctx_mlp", "lang_tokens",
-                                         "lang_dim", "scale_context", "max_batch", "enc_dtype", "streams")]
+                                         "lang_dim", "scale_context", "max_batch", "enc_dtype", "streams", "clip_target")]
 
 
 class hvla_tensor_desc(C.Structure):
@@ -114,6 +114,8 @@ def load_library():
                                     C.POINTER(hvla_train_hyper), vp]
     lib.hvla_train_step.restype = C.c_int
     lib.hvla_train_apply.argtypes = [vp, C.POINTER(hvla_train_buffers), C.POINTER(hvla_train_hyper), vp]
+    lib.hvla_train_accumulate.argtypes = [vp, C.POINTER(hvla_train_buffers), vp, C.c_float, C.POINTER(hvla_train_hyper), vp]
+    lib.hvla_train_accumulate.restype = C.c_int
     lib.hvla_train_apply.restype = C.c_int
     lib.hvla_profile.argtypes = [vp, i32]
     lib.hvla_profile.restype = C.c_int
@@ -143,7 +145,8 @@ class Context:
                                g.dim, g.layers, g.heads, g.mlp, g.horizon, g.action_dim,
                                g.tanh_scale, g.max_action, g.ctx_dim, g.ctx_layers, g.ctx_heads, g.ctx_mlp,
                                g.lang_tokens, g.lang_dim, int(g.scale_context), int(max_batch),
-                               HVLA_ENC_BF16 if enc_dtype == "bf16" else HVLA_ENC_F16, int(streams))
+                               HVLA_ENC_BF16 if enc_dtype == "bf16" else HVLA_ENC_F16, int(streams),
+                               int(getattr(g, "clip_target", True)))
         self.geometry, self.device, self.max_batch, self.enc_dtype = g, device, max_batch, enc_dtype
         h = C.c_void_p()
         rc = self.lib.hvla_create(C.byref(self.cfg), device, C.byref(h))
@@ -259,6 +262,10 @@ class Context:
 
     def train_apply(self, buf, hyper, stream=0):
         self._check(self.lib.hvla_train_apply(self.h, C.byref(buf), C.byref(hyper), C.c_void_p(stream)), "hvla_train_apply")
+
+    def train_accumulate(self, buf, acc_ptr, inv_k, hyper, stream=0):
+        self._check(self.lib.hvla_train_accumulate(self.h, C.byref(buf), C.c_void_p(acc_ptr), C.c_float(inv_k), C.byref(hyper),
+                                                   C.c_void_p(stream)), "hvla_train_accumulate")
 
     def ensemble_reset(self, w, stream=0):
         self._check(self.lib.hvla_ensemble_reset(self.h, w, C.c_void_p(stream)), "hvla_ensemble_reset")

@@ -39,6 +39,7 @@ class Geometry:
     action_dim: int = 7
     tanh_scale: float = 5.0
     max_action: float = 5.0
+    clip_target: bool = True    # MixActionHead.loss clips the action target to +-max_action (action_heads.py:499-500)
     # hypernetwork (README.md:33-44)
     ctx_dim: int = 128          # C
     ctx_layers: int = 6
@@ -235,7 +236,7 @@ def default_config(g: Geometry = FULL, dataset_name: str = "bridge_dataset") -> 
                             use_differential_transformer=False, return_attention_map=False,
                             add_positional_embedding=True, include_class_token=False),
             action_head_kwargs=dict(token_per_horizon=False, squash_continuous_action=True,
-                                    tanh_scaling_factor=g.tanh_scale, clip_target=True,
+                                    tanh_scaling_factor=g.tanh_scale, clip_target=g.clip_target,
                                     max_action=g.max_action, hidden_dims=())),
         geometry=dict(image_size=g.image_size, patch=g.patch, enc_dim=g.enc_dim,
                       enc_layers=g.enc_layers, enc_heads=g.enc_heads, enc_mlp=g.enc_mlp,
@@ -260,6 +261,9 @@ def geometry_from_config(cfg: Dict) -> Geometry:
                              f"(README.md:33-44 uses {want!r})")
     if a.get("token_per_horizon") or a.get("hidden_dims"):
         raise ValueError("token_per_horizon / hidden_dims action heads are not built")
+    if not a.get("squash_continuous_action", True):
+        raise ValueError("squash_continuous_action=False is not built: the mix head kernels apply tanh(x / s) * max_action "
+                         "(action_heads.py:469-470)")
     ge = cfg.get("geometry", {})
     ce = h["context_encoder_kwargs"]
     return Geometry(
@@ -269,6 +273,7 @@ def geometry_from_config(cfg: Dict) -> Geometry:
         dim=v["hidden_dim"], layers=v["num_layers"], heads=v["num_heads"], mlp=v["mlp_dim"],
         horizon=b["action_horizon"], action_dim=b["action_dim"],
         tanh_scale=a.get("tanh_scaling_factor", 5.0), max_action=a.get("max_action", 5.0),
+        clip_target=bool(a.get("clip_target", True)),                  # action_heads.py:408 default True
         ctx_dim=h["context_embedding_dim"], ctx_layers=ce["num_layers"],
         ctx_heads=ce["num_attention_heads"], ctx_mlp=ce["mlp_dim"],
         lang_tokens=ge.get("lang_tokens", 32), lang_dim=ge.get("lang_dim", 768),

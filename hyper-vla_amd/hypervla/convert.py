@@ -55,6 +55,96 @@ def load_jax_pickle(path_or_bytes) -> Any:
         return _JaxFreeUnpickler(f).load()
 
 
+# ------------------------------------------------------------------------------------------------ flax msgpack (example_batch)
+# `example_batch.msgpack` is written with flax.serialization.msgpack_serialize (hypervla/model.py:270-274) and read back in
+# load_pretrained (:165-169).  The wire format (flax/serialization.py, flax 0.8.1): plain msgpack maps / lists / scalars;
+# a numpy or jax array is ExtType 1 whose payload is msgpack((shape, dtype.name, raw bytes)); a numpy scalar is ExtType 3
+# with the payload of a 0-d array; a Python complex is ExtType 2 (packed (real, imag)); arrays above ~2 GB are split into
+# a {"__msgpack_chunked_array__": True, "shape": ..., "chunks": [...]} map.  No flax / jax needed.
+_EXT_NDARRAY, _EXT_COMPLEX, _EXT_NPSCALAR = 1, 2, 3
+
+
+def _unpack_ndarray(payload: bytes) -> np.ndarray:
+    import msgpack
+    shape, dtype_name, buf = msgpack.unpackb(payload, raw=True)
+    dtype_name = dtype_name.decode() if isinstance(dtype_name, bytes) else dtype_name
+    if dtype_name == "bfloat16":                       # not a numpy dtype: widen to float32
+        u = np.frombuffer(buf, dtype=np.uint16).astype(np.uint32) << 16
+        return u.view(np.float32).reshape(shape)
+    return np.frombuffer(buf, dtype=np.dtype(dtype_name)).reshape(shape).copy()
+
+
+def _ext_hook(code: int, data: bytes):
+    import msgpack
+    if code == _EXT_NDARRAY:
+        return _unpack_ndarray(data)
+    if code == _EXT_NPSCALAR:
+        return _unpack_ndarray(data)[()]
+    if code == _EXT_COMPLEX:
+        re, im = msgpack.unpackb(data)
+        return complex(re, im)
+    return msgpack.ExtType(code, data)
+
+
+def _unchunk(tree):
+    if isinstance(tree, dict):
+        if tree.get("__msgpack_chunked_array__"):
+            chunks = [tree["chunks"][str(i)] if isinstance(tree["chunks"], dict) else tree["chunks"][i]
+                      for i in range(len(tree["chunks"]))]
+            return np.concatenate([np.asarray(c).reshape(-1) for c in chunks]).reshape(tree["shape"])
+        return {k: _unchunk(v) for k, v in tree.items()}
+    return tree
+
+
+def msgpack_restore(data: bytes) -> Any:
+    """`flax.serialization.msgpack_restore` without flax: bytes -> nested dict of numpy arrays / Python scalars."""
+    import msgpack
+    return _unchunk(msgpack.unpackb(data, ext_hook=_ext_hook, raw=False, strict_map_key=False))
+
+
+def msgpack_serialize(tree: Any) -> bytes:
+    """`flax.serialization.msgpack_serialize` without flax (arrays below the 2 GB chunking threshold)."""
+    import msgpack
+
+    def default(o):
+        if isinstance(o, np.ndarray):
+            return msgpack.ExtType(_EXT_NDARRAY, msgpack.packb((list(o.shape), o.dtype.name, o.tobytes()), use_bin_type=True))
+        if isinstance(o, np.generic):
+            a = np.asarray(o)
+            return msgpack.ExtType(_EXT_NPSCALAR, msgpack.packb((list(a.shape), a.dtype.name, a.tobytes()), use_bin_type=True))
+        if isinstance(o, complex):
+            return msgpack.ExtType(_EXT_COMPLEX, msgpack.packb((o.real, o.imag)))
+        raise TypeError(f"cannot serialise {type(o)}")
+
+    def prep(t):                      # torch tensors / anything array-like -> numpy
+        if isinstance(t, dict):
+            return {str(k): prep(v) for k, v in t.items()}
+        if isinstance(t, (list, tuple)):
+            return [prep(v) for v in t]
+        if isinstance(t, (np.ndarray, np.generic, int, float, bool, str, bytes, complex)) or t is None:
+            return t
+        return np.asarray(t)
+
+    return msgpack.packb(prep(tree), default=default, use_bin_type=True)
+
+
+def load_example_batch(checkpoint_path: str) -> Optional[Dict[str, Any]]:
+    """The `example_batch` of a checkpoint directory (hypervla/model.py:165-169), or None when the file is absent.  As the
+    reference does (:190-192), a missing language `token_embedding` is added as zeros [B, T, 768]."""
+    fp = os.path.join(checkpoint_path, "example_batch.msgpack")
+    if not os.path.exists(fp):
+        return None
+    with open(fp, "rb") as f:
+        eb = msgpack_restore(f.read())
+    try:
+        li = eb["task"]["language_instruction"]
+        if "token_embedding" not in li:
+            li["token_embedding"] = np.zeros(tuple(np.shape(li["input_ids"])) + (768,), np.float32)
+    except (KeyError, TypeError):
+        pass
+    return eb
+
+
 def load_ema_pickle(path: str, coefficient: float = 0.999) -> Dict[str, Any]:
     """The tree the evaluators swap in with ``model.replace(params=EMA_params[f"EMA_{coefficient}"])``."""
     trees = load_jax_pickle(path)

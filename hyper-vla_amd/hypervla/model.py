@@ -103,9 +103,10 @@ class HyperVLA:
     # ------------------------------------------------------------------ construction
     @classmethod
     def load_pretrained(cls, checkpoint_path: str, step: Optional[int] = None, **kw) -> "HyperVLA":
-        """Reads ``config.json``, ``dataset_statistics.json`` and the parameter file written by
-        :meth:`save_pretrained` (``params_<step>.npz`` / ``params.npz``; flat '/'-joined flax names,
-        SURVEY.md §5.4).  Orbax checkpoints need the JAX-side exporter described in INTEGRATION.md."""
+        """Reads ``config.json``, ``example_batch.msgpack`` (flax msgpack, read without flax: hypervla/convert.py),
+        ``dataset_statistics.json`` and the parameter file written by :meth:`save_pretrained` (``params_<step>.npz`` /
+        ``params.npz``; flat '/'-joined flax names) -- the files of hypervla/model.py:152-214 except that
+        the parameters are an npz instead of an Orbax step directory (exporter-only: INTEGRATION.md)."""
         with open(os.path.join(checkpoint_path, "config.json")) as f:
             config = json.load(f)
         if "action_head_kwargs" not in config["base_net_kwargs"]:        # model.py:157-163
@@ -123,7 +124,8 @@ class HyperVLA:
             raise FileNotFoundError(f"no params*.npz under {checkpoint_path} (step={step})")
         with np.load(os.path.join(checkpoint_path, cands[-1])) as z:
             params = {k: z[k] for k in z.files}
-        return cls(config, params, None, stats, **kw)
+        from .convert import load_example_batch
+        return cls(config, params, load_example_batch(checkpoint_path), stats, **kw)
 
     def save_pretrained(self, step: int, checkpoint_path: str):
         os.makedirs(checkpoint_path, exist_ok=True)
@@ -136,6 +138,11 @@ class HyperVLA:
         if self.dataset_statistics is not None and not os.path.exists(sp):
             with open(sp, "w") as f:
                 json.dump(_tree_map(lambda x: np.asarray(x).tolist(), self.dataset_statistics), f)
+        ep = os.path.join(checkpoint_path, "example_batch.msgpack")          # hypervla/model.py:270-274
+        if self.example_batch is not None and not os.path.exists(ep):
+            from .convert import msgpack_serialize
+            with open(ep, "wb") as f:
+                f.write(msgpack_serialize(self.example_batch))
 
     @classmethod
     def from_synthetic(cls, geometry: Geometry = FULL, params: Optional[Dict[str, np.ndarray]] = None, **kw) -> "HyperVLA":

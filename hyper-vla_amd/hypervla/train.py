@@ -96,13 +96,58 @@ def lr_rsqrt(step: int, peak: float, warmup: int = 2000, timescale: int = 10000,
     return peak / float(np.sqrt((s + timescale) / timescale))
 
 
+def weight_decay_mask(g: Geometry, strategy: str, train_encoder: bool = False) -> np.ndarray:
+    """uint8 [n_params]: where `create_optimizer`'s decoupled weight decay applies (octo/utils/train_utils.py:330-375).
+
+    "v5" (the README run, README.md:29): the output heads that generate base-net *kernel* leaves (head kernel and head
+    bias alike: the test is on the head's name), nothing else of the hypernetwork, and EVERY leaf of the shared image
+    encoder.  "v1" (the config default, hypervla_pretrain_config.py:290): every parameter whose path contains "kernel"
+    -- all Dense kernels of the hypernetwork including every output head's, and the encoder leaves named *kernel*."""
+    if strategy not in ("v1", "v5"):
+        raise ValueError(f"weight_decay_strategy {strategy!r}: 'v1' and 'v5' are built (v2/v3/v4 are not)")
+    layout, total = train_param_layout(g, train_encoder)
+    leaves = generated_leaves(g)
+    G = leaves[-1].offset + leaves[-1].size
+    mask = np.zeros(total, np.uint8)
+    cols = np.zeros(G, np.uint8)
+    for l in leaves:
+        if "kernel" in l.flat_name:
+            cols[l.offset:l.offset + l.size] = 1
+    for name, off, shape in layout:
+        n = int(np.prod(shape))
+        if name == "W_cat":                       # [C, G]: the kernels of the 73 output heads
+            mask[off:off + n] = np.tile(cols, shape[0]) if strategy == "v5" else 1
+        elif name == "b_cat":                     # their biases
+            mask[off:off + n] = cols if strategy == "v5" else 0
+        elif name.startswith("encoder_image_encoder_"):
+            mask[off:off + n] = 1 if (strategy == "v5" or "kernel" in name) else 0
+        elif strategy == "v1" and "kernel" in name:
+            mask[off:off + n] = 1
+    return mask
+
+
 class FineTuner:
+    """One optimizer state of the fine-tune step.  Defaults are the README run's (README.md:29-31,61 and
+    scripts/configs/hypervla_pretrain_config.py:286-321): weight_decay_strategy v5, learning rate 3e-4 (rsqrt) for the
+    hypernetwork and 3e-5 for the shared image encoder, base_weight_decay 0, no gradient accumulation, EMA 0.999 started at
+    update 5000 (`ema_start_step`; the EMA is a copy of the parameters at that update and an average afterwards,
+    scripts/train.py:681-690)."""
+
     def __init__(self, model, batch: int, peak_lr: float = 3e-4, weight_decay: float = 0.05, clip: float = 1.0,
                  ema_decay: float = 0.999, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8,
-                 train_encoder: bool = False, base_lr: float = None, base_weight_decay: float = 0.0):
+                 train_encoder: bool = False, base_lr: float = 3e-5, base_weight_decay: float = 0.0,
+                 weight_decay_strategy: str = "v5", ema_start_step: int = 5000, grad_accumulation_steps: int = 1,
+                 accept_baked_position_table: bool = False):
         import torch
         self.torch, self.model, self.g, self.B = torch, model, model.geometry, batch
         self.train_encoder = bool(train_encoder)
+        baked = (model.config or {}).get("position_embeddings_baked_from")
+        if self.train_encoder and baked and not accept_baked_position_table:
+            raise ValueError(
+                f"this checkpoint's DINOv2 position table was baked from {baked} to the run-time grid at conversion time "
+                "(hypervla/convert.py); the reference trains the ORIGINAL table through interpolate_pos_encoding, so its "
+                "gradient and Adam state differ and the result cannot be exported back into a reference-shaped "
+                "checkpoint.  Pass accept_baked_position_table=True to train the baked table anyway (INTEGRATION.md).")
         dev = model.device
         n, G, work, n_hyper = model._ctx.train_sizes(batch, self.train_encoder)
         layout, total = train_param_layout(self.g, self.train_encoder)
@@ -121,27 +166,31 @@ class FineTuner:
         self.actions = torch.zeros(batch, self.g.horizon, self.g.action_dim, **f32)
         self.logits = torch.zeros(batch, self.g.horizon, **f32)
         self.sqsum = torch.zeros(1, **f32)
-        mask = np.zeros(G + (n - n_hyper), np.uint8)
-        for l in generated_leaves(self.g):                     # weight_decay_strategy v5 (train_utils.py:354-363)
-            if "kernel" in l.flat_name:
-                mask[l.offset:l.offset + l.size] = 1
-        if self.train_encoder:                                 # base_weight_decay_mask (train_utils.py:414)
-            for name, off, shape in layout:
-                if off >= n_hyper and "kernel" in name:
-                    mask[G + off - n_hyper:G + off - n_hyper + shape[0]] = 1
-        self.wd_mask = torch.as_tensor(mask).to(dev)
+        self.weight_decay_strategy = weight_decay_strategy
+        self.wd_mask = torch.as_tensor(weight_decay_mask(self.g, weight_decay_strategy, self.train_encoder)).to(dev)
         # the pull towards the pretrained encoder only exists for base_weight_decay > 0 (scripts/train.py:469)
         self.params0 = self.params[n_hyper:].clone() if self.train_encoder and base_weight_decay > 0 else None
-        self.buf = _native.hvla_train_buffers(*[t.data_ptr() if t is not None else None for t in (
-            self.params, self.grads, self.mu, self.nu, self.ema, self.theta, self.dtheta, self.work, self.loss,
-            self.actions, self.logits, self.sqsum, self.wd_mask, self.params0)])
+        self.accum_k = int(grad_accumulation_steps)
+        if self.accum_k < 1:
+            raise ValueError("grad_accumulation_steps >= 1")
+        self.acc = torch.zeros(n, **f32) if self.accum_k > 1 else None
+        self.micro = 0                                  # micro-batches since the last update
+        self.buf = self._buffers(self.grads)
+        self.buf_acc = self._buffers(self.acc) if self.acc is not None else None
         self.hy = dict(b1=b1, b2=b2, eps=eps, weight_decay=weight_decay, clip=clip, ema_decay=ema_decay,
                        base_weight_decay=base_weight_decay)
-        self.peak_lr, self.base_peak_lr, self.step_count = peak_lr, (peak_lr if base_lr is None else base_lr), 0
+        self.peak_lr, self.base_peak_lr, self.step_count = peak_lr, base_lr, 0
+        self.ema_start_step = int(ema_start_step)
 
-    def _hyper(self, lr, forward_only=False, base_lr=None):
+    def _buffers(self, grads):
+        return _native.hvla_train_buffers(*[t.data_ptr() if t is not None else None for t in (
+            self.params, grads, self.mu, self.nu, self.ema, self.theta, self.dtheta, self.work, self.loss,
+            self.actions, self.logits, self.sqsum, self.wd_mask, self.params0)])
+
+    def _hyper(self, lr, forward_only=False, base_lr=None, clip=None, ema=True):
         h = self.hy
-        return _native.hvla_train_hyper(lr, h["b1"], h["b2"], h["eps"], h["weight_decay"], h["clip"], h["ema_decay"],
+        return _native.hvla_train_hyper(lr, h["b1"], h["b2"], h["eps"], h["weight_decay"], h["clip"] if clip is None else clip,
+                                        h["ema_decay"] if ema else 0.0,
                                         self.step_count, int(forward_only), lr if base_lr is None else base_lr,
                                         h["base_weight_decay"], int(self.train_encoder))
 
@@ -177,15 +226,39 @@ class FineTuner:
         m._ctx.train_step(self.buf, ptrs, self.B, self._hyper(0.0, forward_only), m._stream())
         return self.loss
 
-    def apply(self, lr=None, base_lr=None):
+    def all_reduce_gradient(self):
+        """`pmean(grads)` of scripts/train.py:460 (RCCL over xGMI on the GPU box; gloo in the CPU tests)."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads)                               # RCCL; pmean(grads) of scripts/train.py:460
+            dist.all_reduce(self.grads)
             self.grads /= dist.get_world_size()
+
+    def apply(self, lr=None, base_lr=None):
+        """Gradient all-reduce, then the optimizer: chain(clip_by_global_norm, [MultiSteps](adamw)) and the EMA.  With
+        grad_accumulation_steps = k the clipped gradient of every micro-batch goes into a running mean and parameters move
+        on every k-th call only (optax.MultiSteps, octo/utils/train_utils.py:420-421); returns True when they moved."""
+        self.all_reduce_gradient()
+        ctx, st = self.model._ctx, self.model._stream()
+        if self.accum_k > 1:
+            if self.micro == 0:
+                self.acc.zero_()
+            ctx.train_accumulate(self.buf, self.acc.data_ptr(), 1.0 / self.accum_k, self._hyper(0.0), st)
+            self.micro += 1
+            if self.micro < self.accum_k:
+                return False
+            self.micro = 0
         lr = lr_rsqrt(self.step_count, self.peak_lr) if lr is None else lr
         base_lr = lr_rsqrt(self.step_count, self.base_peak_lr) if base_lr is None else base_lr
-        self.model._ctx.train_apply(self.buf, self._hyper(lr, base_lr=base_lr), self.model._stream())
+        update = self.step_count + 1                   # scripts/train.py:679 current_update_step
+        ema_on = update > self.ema_start_step
+        if self.accum_k > 1:                           # the micro-gradients were clipped one by one
+            ctx.train_apply(self.buf_acc, self._hyper(lr, base_lr=base_lr, clip=float("inf"), ema=ema_on), st)
+        else:
+            ctx.train_apply(self.buf, self._hyper(lr, base_lr=base_lr, ema=ema_on), st)
+        if update == self.ema_start_step:              # scripts/train.py:682-688: the EMA starts as a copy
+            self.ema.copy_(self.params)
         self.step_count += 1
+        return True
 
     def step(self, instruction_dict, initial_state, images, batch, lr=None, base_lr=None):
         obs = images if self.train_encoder else self.model.encode_images(images)

@@ -57,6 +57,8 @@ typedef struct hvla_config {
   int32_t enc_dtype;                         /* HVLA_ENC_F16 | HVLA_ENC_BF16                    */
   int32_t streams;                           /* 1 (default, 0 = 1) or 2: hvla_step runs the two halves of a batch of
                                                 >= 64 episodes on two streams, forked from / joined to the caller's  */
+  int32_t clip_target;                       /* action_head_kwargs.clip_target (action_heads.py:408,499-500): the loss clips
+                                                the action target to +-max_action iff non-zero                        */
 } hvla_config;
 
 /* One named float32 tensor of the hypernetwork checkpoint, HOST memory, reference naming
@@ -131,7 +133,7 @@ int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const fl
 /* Replaces: MixActionHead.loss evaluated per sample (vmap of sample_loss_fn) on the policy's outputs
  * (hypervla/components/action_heads.py:474-522, scripts/train.py:326-346): the forward half of the
  * fine-tune step.  actions / logits as written by hvla_policy / hvla_step; target f32 [B, horizon,
- * action_dim] (clipped to +-max_action inside, clip_target=True); timestep_mask u8 [B];
+ * action_dim] (clipped to +-max_action inside iff hvla_config.clip_target); timestep_mask u8 [B];
  * action_mask u8 [B, horizon, action_dim]; loss f32 [B] = 6 * masked-MSE + masked sigmoid-BCE.     */
 int hvla_loss(hvla_ctx* ctx, const float* actions, const float* gripper_logits, const float* target,
               const uint8_t* timestep_mask, const uint8_t* action_mask, float* loss, int32_t B,
@@ -159,8 +161,8 @@ typedef struct hvla_train_buffers {
   float* actions;          /* [B, horizon, action_dim] or NULL                                */
   float* logits;           /* [B, horizon] or NULL                                            */
   float* sqsum;            /* [1] scratch for the global gradient norm                        */
-  const uint8_t* wd_mask;  /* [G] 1 where the generated leaf is a base-net kernel (v5 mask);  */
-                           /*   + [n_encoder] 1 on shared "kernel" leaves when train_encoder   */
+  const uint8_t* wd_mask;  /* [n_params] 1 where decoupled weight decay applies (the caller builds  */
+                           /*   the mask of its weight_decay_strategy, train_utils.py:330-375)     */
   const float* params0;    /* [n_encoder] pretrained encoder weights (delta decay) or NULL     */
 } hvla_train_buffers;
 typedef struct hvla_train_hyper {
@@ -179,6 +181,11 @@ int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* t
                     const uint8_t* images, const float* target, const uint8_t* timestep_mask,
                     const uint8_t* action_mask, int32_t B, const hvla_train_hyper* hyper, void* stream);
 int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_train_hyper* hyper, void* stream);
+/* Replaces: one micro-step of optax.MultiSteps under the reference's chain(clip_by_global_norm, MultiSteps(adamw))
+ * (octo/utils/train_utils.py:420-426, grad_accumulation_steps > 1): acc += clip_by_global_norm(buf->grads) * inv_k.
+ * After k micro-steps the caller runs hvla_train_apply with `grads` pointing at acc and hyper.clip = +inf.        */
+int hvla_train_accumulate(hvla_ctx* ctx, const hvla_train_buffers* buf, float* acc, float inv_k,
+                          const hvla_train_hyper* hyper, void* stream);
 
 /* Replaces: InferenceWrapper._resize_image (data/utils/hypervla_interface.py:89-121): optionally
  * tf.image.resize_with_pad(image, 256, 320) (bilinear, zero padding; `padded_resize`), then

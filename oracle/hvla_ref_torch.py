@@ -247,7 +247,7 @@ def mix_loss(g, cont, logits, actions, timestep_pad_mask, action_pad_mask, clip_
 
 
 def train_loss_and_grads(params, g, leaves, instruction_dict, initial_state, tokens, batch, dtype=torch.float64,
-                         images=None, enc_shapes=None):
+                         images=None, enc_shapes=None, clip_target=None):
     """Loss and d(loss)/d(HN params): autograd through hypernetwork -> generated theta -> per-sample policy -> mix
     loss.  With `images` (and `enc_shapes`) the DINOv2 encoder is part of the graph
     (base_vit.py:128 `fine_tune_pretrained_image_encoder=True`) and the returned dict also holds the gradient of every
@@ -275,7 +275,10 @@ def train_loss_and_grads(params, g, leaves, instruction_dict, initial_state, tok
     else:
         tok_t = torch.as_tensor(np.asarray(tokens)).to(dtype)
     act, logit, _ = PolicyRef(g, leaves)(theta, tok_t)
-    per, loss = mix_loss(g, act[..., :-1], logit, batch["action"], batch["timestep_pad_mask"], batch["action_pad_mask"])
+    if clip_target is None:
+        clip_target = bool(getattr(g, "clip_target", True))
+    per, loss = mix_loss(g, act[..., :-1], logit, batch["action"], batch["timestep_pad_mask"], batch["action_pad_mask"],
+                         clip_target=clip_target)
     wrt = [hn.p[k] for k in names]
     enc_named = list(enc.named_parameters()) if enc is not None else []
     grads = torch.autograd.grad(loss, wrt + [q for _, q in enc_named], allow_unused=True)

@@ -165,3 +165,34 @@ def test_t5_state_dict_names():
     assert set(got) == set(t5_param_shapes(t))
     np.testing.assert_array_equal(got["encoder/block/1/layer/1/DenseReluDense/wi/kernel"],
                                   m.state_dict()["encoder.block.1.layer.1.DenseReluDense.wi.weight"].numpy().T)
+
+
+def test_example_batch_msgpack_without_flax(tmp_path):
+    """`example_batch.msgpack` (hypervla/model.py:165-169,270-274) in flax's msgpack dialect: arrays are ExtType 1 with the
+    payload msgpack((shape, dtype name, raw bytes)).  The first literal below is that layout written out by hand for
+    np.array([1, 2, 3], int32) inside {"a": ...}; then a round trip of an OXE-shaped batch, and the token_embedding the
+    reference adds when the file lacks it (:190-192)."""
+    from hypervla.convert import load_example_batch, msgpack_restore, msgpack_serialize
+    wire = bytes.fromhex("81" "a161"                      # map of 1: "a"
+                         "c7" "18" "01"                   # ext8, 24 payload bytes, type 1 (ndarray)
+                         "93" "91" "03"                   # (shape = [3],
+                         "a5" "696e743332"                #  "int32",
+                         "c4" "0c" "010000000200000003000000")   # bin8, 12 bytes)
+    got = msgpack_restore(wire)
+    assert got["a"].dtype == np.int32 and got["a"].tolist() == [1, 2, 3]
+    assert msgpack_serialize({"a": np.array([1, 2, 3], np.int32)}) == wire
+    eb = {"observation": {"image_primary": np.arange(2 * 1 * 4 * 4 * 3, dtype=np.uint8).reshape(2, 1, 4, 4, 3),
+                          "timestep_pad_mask": np.ones((2, 1), bool)},
+          "task": {"language_instruction": {"input_ids": np.arange(64).reshape(2, 32), "attention_mask": np.ones((2, 32), np.int64)}},
+          "initial_state": {"image_primary": np.zeros((2, 1, 4, 4, 3), np.uint8)},
+          "action": np.linspace(-1, 1, 2 * 1 * 4 * 7, dtype=np.float32).reshape(2, 1, 4, 7), "dataset_name": "bridge_dataset"}
+    (tmp_path / "example_batch.msgpack").write_bytes(msgpack_serialize(eb))
+    back = load_example_batch(str(tmp_path))
+    np.testing.assert_array_equal(back["observation"]["image_primary"], eb["observation"]["image_primary"])
+    np.testing.assert_array_equal(back["action"], eb["action"])
+    assert back["observation"]["timestep_pad_mask"].dtype == bool and back["dataset_name"] == "bridge_dataset"
+    assert back["task"]["language_instruction"]["token_embedding"].shape == (2, 32, 768)
+    assert load_example_batch(str(tmp_path / "nowhere")) is None
+    # bfloat16 leaves (not a numpy dtype) come back as float32
+    bf = msgpack_restore(bytes.fromhex("81a162" "c7" "0f" "01" "93" "91" "01" "a8" + "bfloat16".encode().hex() + "c4" "02" "803f"))
+    assert bf["b"].dtype == np.float32 and bf["b"].tolist() == [1.0]

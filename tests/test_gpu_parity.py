@@ -472,6 +472,36 @@ def test_full_size_batch_properties():
     same(pa, pl, full_a[perm], full_l[perm])
 
 
+def test_batch_of_1024_episodes_per_gpu():
+    """BASELINE configs[3] per-GPU share (8 GPUs x 1024 episodes): the 1024-episode step runs (multi-round persistent GEMM
+    grids, 3 GB of workspace), obeys the head's range contract, and every episode equals -- bit for bit -- the same episode
+    in a batch of 256 at another position and in a batch of 8 (gemm256p one-workgroup-per-tile form) and alone (64x64 kernel)."""
+    _need_gpu()
+    from hypervla import synthetic as syn
+    from hypervla.config import FULL
+    from hypervla.model import HyperVLA
+    g, B = FULL, 1024
+    m = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    li = ins["language_instruction"]
+
+    def run(idx):
+        sub_ins = {"language_instruction": {k: np.asarray(v)[idx] for k, v in li.items()}}
+        sub_st = {"patch_embeddings": st["patch_embeddings"][idx], "pad_mask_dict": {"image_primary": np.ones((len(idx), 1))}}
+        w, tasks, _ = m.create_tasks(instruction_dict=sub_ins, initial_state=sub_st)
+        a, inter = m.sample_actions(im[idx], sub_ins, tasks, np.ones((len(idx), 1)), base_params=w)
+        return np.asarray(a), np.asarray(inter["gripper_logits"])
+
+    full_a, full_l = run(np.arange(B))
+    assert full_a.shape == (B, g.horizon, g.action_dim) and np.isfinite(full_a).all() and np.isfinite(full_l).all()
+    assert np.abs(full_a[..., :6]).max() <= g.max_action and set(np.unique(full_a[..., 6])) <= {0.0, 1.0}
+    assert len({full_a[b].tobytes() for b in range(B)}) == B
+    for idx in (np.arange(700, 956), np.array([1023, 5, 512, 77, 300, 301, 0, 999]), np.array([640])):
+        a, l = run(idx)
+        np.testing.assert_array_equal(a, full_a[idx])
+        np.testing.assert_array_equal(l, full_l[idx])
+
+
 def test_policy_kernel_is_run_to_run_deterministic(full):
     """Regression: the -O3 schedule of the policy megakernel once gave a slightly different action chunk in ~4 % of
     launches on identical inputs (policy.hip `mfma_tied`).  2000 single-episode launches and 60 launches of 64 episodes into

@@ -23,7 +23,7 @@ def setup():
     batch = syn.synthetic_action_batch(B, g)
     tok = onp.dinov2(P, g, dict(encoder_leaves(g)), onp.normalize_images(im[:, 0]))[:, 1:]      # frozen tokens (oracle)
     per, loss, grads = ot.train_loss_and_grads(P, g, leaves, ins, st, tok, batch)
-    ft = FineTuner(model, B)
+    ft = FineTuner(model, B, ema_start_step=0)          # EMA from the first update on (the reference's default is 5000)
     return dict(g=g, B=B, model=model, ft=ft, ins=ins, st=st, im=im, batch=batch, tok=tok, per=per.numpy(),
                 loss=float(loss), grads={k: v.numpy() for k, v in grads.items()}, P=P)
 
@@ -54,6 +54,37 @@ def test_train_gradients_match_autograd(setup):
     worst.sort(reverse=True)
     print("worst relative gradient errors:", [(f"{r:.2e}", k) for r, k, _, _ in worst[:5]])
     assert worst[0][0] <= 2e-3, worst[:5]
+
+
+def test_unclipped_targets_when_the_checkpoint_says_so(setup):
+    """action_head_kwargs.clip_target=False (what load_pretrained injects for checkpoints without the key,
+    hypervla/model.py:157-163): the loss and its gradient use the raw target (action_heads.py:499-500).  The synthetic
+    batch has targets beyond +-max_action, so the two settings differ."""
+    import dataclasses
+    from hypervla.config import default_config, generated_leaves
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner, unpack_params
+    from oracle import hvla_ref_torch as ot
+    s = setup
+    g2 = dataclasses.replace(s["g"], clip_target=False)
+    assert (np.abs(s["batch"]["action"][..., :6]) > g2.max_action).any()
+    m2 = HyperVLA(default_config(g2), s["P"], None, None, max_batch=s["B"])
+    assert m2.geometry.clip_target is False
+    per, loss, grads = ot.train_loss_and_grads(s["P"], g2, generated_leaves(g2), s["ins"], s["st"], s["tok"], s["batch"])
+    assert abs(float(loss) - s["loss"]) > 1e-3                      # not the clipped loss
+    ft = FineTuner(m2, s["B"])
+    got_loss = ft.forward_backward(s["ins"], s["st"], s["tok"].astype(np.float32), s["batch"])
+    np.testing.assert_allclose(got_loss.cpu().numpy(), per.numpy(), rtol=2e-4, atol=2e-5)
+    got = unpack_params(g2, ft.grads.cpu().numpy())
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    for k in ("output_head_action_head_continuous_head_kernel/kernel", "Transformer_0/encoder_norm/scale"):
+        ref = grads[k].numpy()
+        d = np.abs(got[k].reshape(ref.shape) - ref).max()
+        assert d <= 2e-3 * max(np.abs(ref).max(), 1e-4 * gmax), (k, d)
+    # the stand-alone loss entry point follows the same switch
+    act, lg = m2.policy_from_tokens(s["tok"].astype(np.float32), m2.create_tasks(instruction_dict=s["ins"], initial_state=s["st"])[0])
+    l2, _ = m2.action_loss(act, lg, s["batch"])
+    np.testing.assert_allclose(l2.cpu().numpy(), per.numpy(), rtol=2e-4, atol=2e-5)
 
 
 def test_adamw_step_matches_reference_update(setup):
@@ -172,9 +203,13 @@ def test_encoder_gradients_full_geometry():
     _encoder_case(FULL, 1, 3e-3)
 
 
-def test_two_group_optimizer_and_delta_decay():
-    """multi_transform{generated: AdamW(lr, v5 mask), shared: AdamW(base_lr, kernel mask)} under one global-norm clip,
-    plus the pull towards the pretrained encoder (train_utils.py:411-426, scripts/train.py:465-471)."""
+@pytest.mark.parametrize("strategy", ["v5", "v1"])
+def test_two_group_optimizer_and_delta_decay(strategy):
+    """multi_transform{generated: AdamW(lr, mask), shared: AdamW(base_lr, mask)} under one global-norm clip, plus the pull
+    towards the pretrained encoder (train_utils.py:330-426, scripts/train.py:465-471), for both weight-decay strategies:
+    v5 (README run) decays the kernel-generating output heads and EVERY image-encoder leaf, v1 every *kernel* parameter.
+    Under v5 with base_weight_decay > 0 a shared bias / norm / LayerScale leaf that sits at its pretrained value sees
+    +wd p - wd p0 = 0, i.e. it does not drift."""
     from hypervla import synthetic as syn
     from hypervla.config import MID, generated_leaves
     from hypervla.model import HyperVLA
@@ -184,8 +219,15 @@ def test_two_group_optimizer_and_delta_decay():
     ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
     batch = syn.synthetic_action_batch(B, g)
     wd, bwd, lr, blr, b1, b2, eps = 0.05, 0.01, 1e-3, 2e-4, 0.9, 0.999, 1e-8
-    ft = FineTuner(model, B, weight_decay=wd, train_encoder=True, base_weight_decay=bwd)
-    ft.params[ft.n_hyper:] += 0.01 * torch.randn_like(ft.params[ft.n_hyper:])      # move away from the pretrained point
+    ft = FineTuner(model, B, weight_decay=wd, train_encoder=True, base_weight_decay=bwd, weight_decay_strategy=strategy)
+    assert ft.base_peak_lr == 3e-5                                      # hypervla_pretrain_config.py:292-298
+    layout, total = train_param_layout(g, True)
+    nh, G = ft.n_hyper, ft.G
+    moved = torch.zeros_like(ft.params[nh:])
+    for name, off, shape in layout:                                       # move the encoder KERNELS away from the pretrained point
+        if off >= nh and "kernel" in name:
+            moved[off - nh:off - nh + int(np.prod(shape))] = 0.01
+    ft.params[nh:] += moved * torch.randn_like(moved)
     ft.forward_backward(ins, st, im, batch)
     p0 = ft.params.cpu().numpy().astype(np.float64)
     pre = ft.params0.cpu().numpy().astype(np.float64)
@@ -193,8 +235,6 @@ def test_two_group_optimizer_and_delta_decay():
     ft.apply(lr=lr, base_lr=blr)
     gc = gr * min(1.0, 1.0 / np.sqrt((gr * gr).sum()))
     upd = ((1 - b1) * gc / (1 - b1)) / (np.sqrt((1 - b2) * gc * gc / (1 - b2)) + eps)
-    layout, total = train_param_layout(g, True)
-    nh, G = ft.n_hyper, ft.G
     cols = np.zeros(G, bool)
     for l in generated_leaves(g):
         if "kernel" in l.flat_name:
@@ -204,12 +244,95 @@ def test_two_group_optimizer_and_delta_decay():
         n = int(np.prod(shape))
         sl = slice(off, off + n)
         if off < nh:
-            m = np.tile(cols, shape[0]) if name == "W_cat" else cols if name == "b_cat" else np.zeros(n, bool)
+            if strategy == "v5":
+                m = np.tile(cols, shape[0]) if name == "W_cat" else cols if name == "b_cat" else np.zeros(n, bool)
+            else:
+                m = np.ones(n, bool) if (name == "W_cat" or "kernel" in name) else np.zeros(n, bool)
             want[sl] = p0[sl] - lr * (upd[sl] + wd * p0[sl] * m)
         else:
-            k = 1.0 if "kernel" in name else 0.0
+            k = 1.0 if (strategy == "v5" or "kernel" in name) else 0.0
             want[sl] = p0[sl] - blr * (upd[sl] + bwd * k * p0[sl] - bwd * pre[off - nh:off - nh + n])
+            if strategy == "v5" and "kernel" not in name:                 # no drift of an un-moved leaf beyond Adam's own step
+                np.testing.assert_allclose(want[sl], p0[sl] - blr * upd[sl], rtol=0, atol=1e-12)
     np.testing.assert_allclose(ft.params.cpu().numpy(), want, rtol=0, atol=2e-6)
+
+
+def test_gradient_accumulation_and_ema_start(setup):
+    """optax.MultiSteps under chain(clip, MultiSteps(adamw)) (train_utils.py:420-426): with k = 2 the parameters move on every
+    second micro-batch only, by AdamW on the mean of the two CLIPPED gradients; the EMA is a copy of the parameters at
+    update `ema_start_step` and an average after it (scripts/train.py:681-690)."""
+    from hypervla import synthetic as syn
+    from hypervla.train import FineTuner
+    s = setup
+    g, B = s["g"], s["B"]
+    ft = FineTuner(s["model"], B, grad_accumulation_steps=2, ema_start_step=2, weight_decay=0.0)
+    tok = s["tok"].astype(np.float32)
+    b2 = syn.synthetic_action_batch(B, g, rank=1)
+    p0 = ft.params.clone()
+    ft.forward_backward(s["ins"], s["st"], tok, s["batch"])
+    g1 = ft.grads.double().clone()
+    assert ft.apply(lr=1e-3) is False and torch.equal(ft.params, p0) and ft.step_count == 0
+    ft.forward_backward(s["ins"], s["st"], tok, b2)
+    g2 = ft.grads.double().clone()
+    assert ft.apply(lr=1e-3) is True and ft.step_count == 1
+    clipn = lambda v: v * min(1.0, 1.0 / float(v.norm()))
+    mean = (clipn(g1) + clipn(g2)) / 2
+    want = p0.double() - 1e-3 * mean / (mean.abs() + 1e-8)              # first AdamW step: m / (sqrt(v) + eps) = g / (|g| + eps)
+    # (where the two clipped gradients cancel to below Adam's eps the update g / (|g| + eps) amplifies f32 rounding of g)
+    ok = mean.abs() > 1e-6
+    err = ((ft.params.double() - want).abs() * ok)
+    assert float(err.max()) <= 2e-6 and float(ok.double().mean()) > 0.9, (float(err.max()), float(ok.double().mean()))
+    assert float((ft.params.double() - p0.double()).abs().max()) <= 1e-3 * (1 + 1e-3)       # |update| <= lr everywhere
+    assert torch.equal(ft.ema, p0)                                       # update 1 < ema_start_step: untouched
+    for _ in range(2):
+        ft.forward_backward(s["ins"], s["st"], tok, s["batch"]); ft.apply(lr=1e-3)
+    assert ft.step_count == 2 and torch.equal(ft.ema, ft.params)         # update 2 == start: a copy
+    p2 = ft.params.clone()
+    for _ in range(2):
+        ft.forward_backward(s["ins"], s["st"], tok, s["batch"]); ft.apply(lr=1e-3)
+    np.testing.assert_allclose(ft.ema.cpu().numpy(), (0.999 * p2.double() + 0.001 * ft.params.double()).cpu().numpy(), atol=2e-6)
+
+
+@pytest.mark.timeout(900)
+def test_config5_per_gpu_step_at_full_geometry():
+    """BASELINE configs[4] per-GPU share: README geometry, 32 samples, image encoder trained (113 M parameters).  No oracle
+    at this size; properties: the loss of the fused step equals the forward-only loss of the inference-precision model to
+    f32 accuracy class, the flat gradient is finite and equals the mean of the two half-batch gradients (what `pmean` over
+    two ranks would give, scripts/train.py:453-460), and one optimizer step moves both parameter groups."""
+    from hypervla import synthetic as syn
+    from hypervla.config import FULL
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner
+    g, B = FULL, 32
+    model = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    batch = syn.synthetic_action_batch(B, g)
+    ft = FineTuner(model, B, train_encoder=True)
+    assert ft.n - ft.n_hyper > 86_000_000                                   # the DINOv2-base leaves are in the vector
+    loss = ft.forward_backward(ins, st, im, batch).clone()
+    assert torch.isfinite(loss).all() and torch.isfinite(ft.grads).all()
+    gfull = ft.grads.double().clone()
+    # the same step's forward against the inference path (fp16 encoder): per-sample losses agree to the encoder's precision
+    w, tasks, _ = model.create_tasks(instruction_dict=ins, initial_state=st)
+    act, inter = model.sample_actions(torch.as_tensor(im[:, 0]).to(model.device), ins, tasks, None, w)
+    l_inf, _ = model.action_loss(act, inter["gripper_logits"], batch)
+    np.testing.assert_allclose(loss.cpu().numpy(), l_inf.cpu().numpy(), rtol=5e-3, atol=5e-3)
+    # gradient of the batch = mean of the gradients of its two halves
+    half = FineTuner(model, B // 2, train_encoder=True)
+    acc = torch.zeros_like(gfull)
+    for lo in (0, B // 2):
+        sl = slice(lo, lo + B // 2)
+        sub_ins = {"language_instruction": {k: np.asarray(v)[sl] for k, v in ins["language_instruction"].items()}}
+        sub_st = {"patch_embeddings": st["patch_embeddings"][sl]}
+        sub_b = {k: v[sl] for k, v in batch.items()}
+        half.forward_backward(sub_ins, sub_st, im[sl], sub_b)
+        acc += half.grads.double() / 2
+    scale = float(gfull.abs().max())
+    assert float((acc - gfull).abs().max()) <= 2e-3 * scale, (float((acc - gfull).abs().max()), scale)
+    before = ft.params.clone()
+    ft.apply()
+    moved = (ft.params - before).abs()
+    assert float(moved[:ft.n_hyper].max()) > 0 and float(moved[ft.n_hyper:].max()) > 0
 
 
 def test_encoder_training_reduces_loss():

@@ -135,3 +135,30 @@ def test_batched_ensembler_equals_unbatched():
         got = a.ensemble_action(x)
         for i in range(3):
             np.testing.assert_allclose(got[i], b[i].ensemble_action(x[i]), atol=1e-12)
+
+
+def test_weight_decay_masks_follow_the_reference_strategies():
+    """octo/utils/train_utils.py:330-375: v5 = output heads that generate base-net kernels + every image-encoder leaf; v1 =
+    every parameter whose path contains "kernel"."""
+    from hypervla.config import MID, generated_leaves
+    from hypervla.train import train_param_layout, weight_decay_mask
+    g = MID
+    layout, total = train_param_layout(g, True)
+    v5, v1 = weight_decay_mask(g, "v5", True), weight_decay_mask(g, "v1", True)
+    assert v5.shape == v1.shape == (total,)
+    leaves = generated_leaves(g)
+    G = leaves[-1].offset + leaves[-1].size
+    kernel_cols = sum(l.size for l in leaves if "kernel" in l.flat_name)
+    for name, off, shape in layout:
+        n = int(np.prod(shape))
+        a, b = v5[off:off + n], v1[off:off + n]
+        if name == "W_cat":
+            assert a.sum() == shape[0] * kernel_cols and b.all()
+        elif name == "b_cat":
+            assert a.sum() == kernel_cols and not b.any()
+        elif name.startswith("encoder_image_encoder_"):
+            assert a.all() and bool(b.all()) == ("kernel" in name) and (b.all() or not b.any())
+        else:                                           # context encoder / projections / position embeddings
+            assert not a.any() and bool(b.all()) == ("kernel" in name)
+    with pytest.raises(ValueError):
+        weight_decay_mask(g, "v3")
