@@ -16,9 +16,10 @@
 //                        QKV    + bias, q * 1/sqrt(hd)        -> 16-bit
 //                        GELU   + bias, exact erf GELU        -> 16-bit
 //                        RES    x += (acc + bias) * layerscale -> f32 residual stream (in place)
-//   colsum / corr      first-order compensation of the WEIGHT rounding: A W = A W16 + A dW with
-//                      dW = W - W16; A dW is replaced by (per-image mean row of A) dW, a [B, N] table that the epilogues
-//                      add instead of the bias.  Rounding a shared weight perturbs every token of an image the same way,
+//   mean rows / corr   first-order compensation of the WEIGHT rounding: A W = A W16 + A dW with
+//                      dW = W - W16; A dW is replaced by (per-image mean row of A) dW, a [B, N] table (gemm64_kernel's
+//                      second problem) that the epilogues add instead of the bias.  The mean rows come out of the kernels
+//                      that write A: layernorm_cs_kernel, attention_kernel, the GELU epilogue.  Rounding a shared weight perturbs every token of an image the same way,
 //                      which the generated policy (it pools the 256 tokens) feels about sqrt(257) times more than the
 //                      independent rounding of activations; the mean row carries most of that coherent part.
 //   layernorm_kernel   f32 rows -> 16-bit rows (eps 1e-6), one wavefront per row; final variant drops the
@@ -78,7 +79,7 @@ __global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-enum { EPI_PATCH = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RES = 3 };
+enum { EPI_PATCH = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RES = 3, EPI_CORR = 4 };   // CORR: out f32 = bias + acc / 4096 (gemm64_kernel's second problem)
 
 struct GemmArgs {
   const void* A;   // 16-bit; logical row m lives at global row row0 + m * row_step, K contiguous
@@ -90,7 +91,13 @@ struct GemmArgs {
   int P, S;              // patches / tokens per image (PATCH row remap; row -> image)
   int qcols;             // QKV: columns < qcols are scaled by qscale
   float qscale;
-  const float* corr = nullptr;   // [B][N] per-image bias row = bias + (mean row of A over the image) . dW (corr_kernel)
+  const float* corr = nullptr;   // [B][N] per-image bias row = bias + (mean row of A over the image) . dW; rows that are an
+                                 // image's CLS token keep the plain bias (one token of 257: nothing coherent to compensate)
+  // gemm64_kernel, second problem in the same launch (blocks >= nb1): corr2[M2][N] = bias + abar2[M2][K] . dW2[N][K] / 4096
+  const void* abar2 = nullptr;
+  const void* dW2 = nullptr;
+  float* corr2 = nullptr;
+  int M2 = 0, nb1 = 0;
   int row0 = 0, row_step = 1;    // gemm64_kernel: the B CLS rows are rows b * S of the activation matrix
   // gemm256p_kernel: tile row t covers global rows tile_row0 + t * tile_stride .. + 255 (image-aligned: 1, S; the patch
   // GEMM's contiguous rows: 0, 256); nbm tile rows, every tile full
@@ -149,7 +156,9 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
         }
         if constexpr (ROWBIAS) {
           brow[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (ok[u][r]) brow[u][r] = *reinterpret_cast<const f32x4*>(g.corr + (uint32_t)(grow / g.S) * (uint32_t)g.N + (uint32_t)n);
+          const int img = grow / g.S;
+          const float* bsrc = grow - img * g.S ? g.corr + (uint32_t)img * (uint32_t)g.N : g.bias;   // CLS row: plain bias
+          if (ok[u][r]) brow[u][r] = *reinterpret_cast<const f32x4*>(bsrc + (uint32_t)n);
         }
       }
 #pragma unroll
@@ -158,6 +167,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if constexpr (EPI == EPI_PATCH) t[c] = acc[c][mp + u] * q + b4[c];      // patch weights are stored x256 (16-bit range)
+        else if constexpr (EPI == EPI_CORR) t[c] = acc[c][mp + u] * (1.f / 4096.f) + b4[c];   // dW is stored x4096
         else if constexpr (ROWBIAS) t[c] = acc[c][mp + u] + f32x4{brow[u][0][c], brow[u][1][c], brow[u][2][c], brow[u][3][c]};
         else t[c] = acc[c][mp + u] + b4[c];
         if constexpr (EPI == EPI_QKV) t[c] *= q;
@@ -180,6 +190,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
 #pragma unroll
           for (int c = 0; c < 4; ++c) x[c] = fmaf(t[c][r], l4[c], x[c]);
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + off[u][r]) = x;
+        } else if constexpr (EPI == EPI_CORR) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + off[u][r]) = f32x4{t[0][r], t[1][r], t[2][r], t[3][r]};
         } else {
           f32x4 x = xin[u][r];
 #pragma unroll
@@ -196,7 +208,7 @@ template <typename Op, int EPI, int MT>
 __device__ __forceinline__ void gemm_epilogue_rows(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
                                                    int fr, int fq) {
   const bool full = m_base + 16 * MT <= g.M;
-  if constexpr (EPI == EPI_PATCH) {
+  if constexpr (EPI == EPI_PATCH || EPI == EPI_CORR) {
     if (full) gemm_epilogue_rows_impl<Op, EPI, MT, true, false>(acc, g, m_base, n_base, fr, fq, nullptr, nullptr);
     else gemm_epilogue_rows_impl<Op, EPI, MT, false, false>(acc, g, m_base, n_base, fr, fq, nullptr, nullptr);
   } else {
@@ -309,14 +321,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 // computes it.
 constexpr int SBM = 64, SBN = 64, SNS = 6;
 template <typename Op, int EPI>
-__global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
   using T = typename Op::elem;
   using X8 = typename Op::x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // SNS x (A 8 KB | W 8 KB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nbm = (g.M + SBM - 1) / SBM;
-  const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
+  const int bm = bid % nbm, bn = bid / nbm;
   const int m0 = bm * SBM, n0 = bn * SBN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
@@ -382,6 +394,20 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
       for (int nt = 0; nt < 4; ++nt) acc[nt][0] = Op::mma16(fa[kk], fw[nt][kk], acc[nt][0]);
   }
   gemm_epilogue_rows<Op, EPI, 1>(acc, g, m0 + wave * 16, n0, fr, fq);
+}
+
+// Blocks [0, nb1): the GEMM itself.  Blocks [nb1, ...): a second, independent problem of the same N and K in the same
+// launch -- the per-image bias rows of the big GEMM that follows (corr2 = bias + abar2 . dW2 / 4096, one row per image),
+// so that the B CLS rows and the B mean rows, both pure latency, cost one launch instead of two.
+template <typename Op, int EPI>
+__global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
+  if (g.nb1 == 0 || (int)blockIdx.x < g.nb1) {
+    gemm64_body<Op, EPI>(g, blockIdx.x);
+  } else {
+    GemmArgs c = g;
+    c.A = g.abar2; c.W = g.dW2; c.out = g.corr2; c.M = g.M2; c.row0 = 0; c.row_step = 1; c.corr = nullptr;
+    gemm64_body<Op, EPI_CORR>(c, blockIdx.x - g.nb1);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -552,6 +578,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
+  int tcount = 0, ptm = 0, pn0 = 0;                 // GELU column means: tiles done by this workgroup, the previous tile
   while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -592,8 +619,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     if constexpr (EPI == EPI_GELU) {
       if (g.colmean) {
         // mean row of this tile's rounded outputs for the fc2 compensation: lane sums its 32 rows (ascending, in the
-        // operand type), the four lanes that share the columns combine in f32 as (fq0 + fq1) + (fq2 + fq3), the two wave
-        // rows as half0 + half1 through LDS (the W half of buffer 1: not part of the next tile's prologue DMA)
+        // operand type), the four lanes that share the columns combine in f32 as (fq0 + fq1) + (fq2 + fq3), and each wave
+        // row parks its half in the 4 KB of LDS behind the K-loop buffers.  The two halves are added (half0 + half1) one
+        // tile LATER, when dozens of barriers have made them visible: no barrier in the epilogue, which would line the two
+        // wave rows up and undo their stagger.
         typename Op::x4 csh;
 #pragma unroll
         for (int c = 0; c < 4; ++c) csh[c] = (T)0.f;
@@ -605,17 +634,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
           cs[c] += __shfl_xor(cs[c], 16, 64);
           cs[c] += __shfl_xor(cs[c], 32, 64);
         }
-        f32x4* xch = reinterpret_cast<f32x4*>(smem + 65536 + 32768) + wn * 16 + fr;
-        if (wm == 1 && fq == 0) *xch = cs;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        HVLA_BAR();
-        if (wm == 0 && fq == 0) {
-          const f32x4 tot = cs + *xch;
+        f32x4* park = reinterpret_cast<f32x4*>(smem + 131072);          // [parity][wave row][wn][fr]
+        if (fq == 0) park[((tcount & 1) * 2 + wm) * 64 + wn * 16 + fr] = cs;
+        if (tcount > 0 && wm == 0 && fq == 0) {                          // the previous tile of this workgroup
+          const int pp = (tcount - 1) & 1;
+          const f32x4 tot = park[(pp * 2 + 0) * 64 + wn * 16 + fr] + park[(pp * 2 + 1) * 64 + wn * 16 + fr];
           typename Op::x4 mo;
 #pragma unroll
           for (int c = 0; c < 4; ++c) mo[c] = (T)(tot[c] * (1.f / 256.f));
-          *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.colmean) + (size_t)ctm * g.N + cn0 + wn * 64 + 4 * fr) = mo;
+          *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.colmean) + (size_t)ptm * g.N + pn0 + wn * 64 + 4 * fr) = mo;
         }
+        ptm = ctm; pn0 = cn0; ++tcount;
       } else {
         gemm_epilogue_rows_impl<Op, EPI, 8, true, false>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
       }
@@ -631,6 +660,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     static_assert(WAITN >= 63 || WAITN == 36, "the s_waitcnt immediates below are written for these two counts");
     if constexpr (WAITN >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+  }
+  if constexpr (EPI == EPI_GELU) {
+    if (g.colmean && tcount > 0) {                   // the last tile's halves: one barrier at the very end
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      HVLA_BAR();
+      if (wm == 0 && fq == 0) {
+        const f32x4* park = reinterpret_cast<const f32x4*>(smem + 131072);
+        const int pp = (tcount - 1) & 1;
+        const f32x4 tot = park[(pp * 2 + 0) * 64 + wn * 16 + fr] + park[(pp * 2 + 1) * 64 + wn * 16 + fr];
+        typename Op::x4 mo;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mo[c] = (T)(tot[c] * (1.f / 256.f));
+        *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.colmean) + (size_t)ptm * g.N + pn0 + wn * 64 + 4 * fr) = mo;
+      }
+    }
   }
 #undef HVLA_BAR
 }
@@ -698,7 +742,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // LayerNorm in front of a GEMM (norm1 / norm2), with the column sums of its output that the GEMM's weight-rounding
-// compensation needs (corr_kernel): workgroup (c, b) = rows [16 c, 16 c + 16) of image b, wave w takes rows 4 w .. 4 w + 3
+// compensation needs (the corr rows of gemm64_kernel): workgroup (c, b) = rows [16 c, 16 c + 16) of image b, wave w takes rows 4 w .. 4 w + 3
 // of them one after the other (the next row's loads in flight), each lane keeps the running sums of its columns, the four
 // waves are combined through LDS in wave order: parts[b][c][E].  Chunks are relative to the image, so the sums do not depend on where the image sits in the
 // batch.  E % 4 == 0, E <= 1024.
@@ -820,7 +864,7 @@ __device__ __forceinline__ float lane_bcast(float v, int l) {
 }
 
 // omean (nullable): [B][E] 16-bit mean over all S tokens of the image of the output, the operand of the out-projection's
-// weight-rounding compensation (corr_kernel): the workgroup owns every row of its 64 columns.
+// weight-rounding compensation (the corr rows of gemm64_kernel): the workgroup owns every row of its 64 columns.
 template <typename Op>
 __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, typename Op::elem* __restrict__ o,
                                  int S, int E, int H, typename Op::elem* __restrict__ omean) {
@@ -1090,76 +1134,6 @@ __global__ __launch_bounds__(256) void mean16_kernel(const float* __restrict__ p
   reinterpret_cast<x4*>(abar + (size_t)b * K)[k4] = o;
 }
 
-// corr_kernel: corr[b][n] = bias[n] + abar[b][:] . dW[n][:] / 4096 on the matrix cores (16x16x32).  A workgroup owns 32
-// images x 64 columns; its NWV waves split K, every wave keeps the loads of UN k-steps in flight (the kernel is pure
-// latency: K = 768 is one round), and the partial tiles are added through LDS in wave order.  dW is stored x4096 so that
-// it stays in the normal range of fp16.  The mean row only needs a few bits (it multiplies a 2^-12 relative quantity), so
-// 16-bit operands are ample here.
-template <typename Op, int NWV>
-__global__ __launch_bounds__(NWV * 64) void corr_kernel(const typename Op::elem* __restrict__ abar,
-                                                        const typename Op::elem* __restrict__ dW, const float* __restrict__ bias,
-                                                        float* __restrict__ corr, int B, int N, int K) {
-  using T = typename Op::elem;
-  using X8 = typename Op::x8;
-  constexpr int UN = 3;
-  __shared__ f32x4 red[NWV][4][64];                  // [wave][n-tile][lane], one m-tile at a time
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
-  const int row = lane & 15, kg = lane >> 4;
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const T* pa[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int b = b0 + mt * 16 + row;
-    pa[mt] = abar + (size_t)(b < B ? b : B - 1) * K + kg * 8;
-  }
-  const T* pw = dW + (size_t)(n0 + row) * K + kg * 8;
-  const int nsteps = K / 32;
-  for (int k0 = wave * UN; k0 < nsteps; k0 += NWV * UN) {
-    X8 af[UN][2], wf[UN][4];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int ks = k0 + u < nsteps ? k0 + u : nsteps - 1;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[u][mt] = *reinterpret_cast<const X8*>(pa[mt] + ks * 32);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) wf[u][nt] = *reinterpret_cast<const X8*>(pw + (size_t)nt * 16 * K + ks * 32);
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      if (k0 + u >= nsteps) break;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = Op::mma16(af[u][mt], wf[u][nt], acc[mt][nt]);
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {                    // one m-tile (16 images) per round through the exchange buffer
-    if (mt) __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) red[wave][nt][lane] = acc[mt][nt];
-    __syncthreads();
-    if (wave < 4) {                                   // wave nt finishes column tile nt
-      const int nt = wave;
-      f32x4 sum = red[0][nt][lane];
-#pragma unroll
-      for (int w = 1; w < NWV; ++w) sum += red[w][nt][lane];
-      const int n = n0 + nt * 16 + row;               // accumulator: column = lane & 15, rows 4 (lane >> 4) + r
-      const float bn = bias[n];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int bi = b0 + mt * 16 + 4 * kg + r;
-        if (bi < B) corr[(size_t)bi * N + n] = fmaf(sum[r], 1.f / 4096.f, bn);
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Range audit of the 16-bit operands (hvla_encode_audit; tests only): largest |value| and number of non-finite values
 // of a buffer, accumulated into slot[0] (float bits, non-negative floats order like unsigned integers) and slot[1].
@@ -1225,7 +1199,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm256p_kernel<Op, EPI_PATCH, true>)) SETA((gemm256p_kernel<Op, EPI_QKV, true>))
     SETA((gemm256p_kernel<Op, EPI_GELU, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true>))
     SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
-    SETA((gemm64_kernel<Op, EPI_RES>))
+    SETA((gemm64_kernel<Op, EPI_RES>)) SETA((gemm64_kernel<Op, EPI_CORR>))
 #undef SETA
     di.attr[opi] = true;
   }
@@ -1234,53 +1208,56 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   constexpr int G64_MAXM = 2047;       // rows up to which a GEMM is cut into 64x64 tiles (pure latency below that)
   constexpr int CAT_COMP = 8;          // HVLA_PROF_COMP
   const bool comp = w.layer[0].dqkv != nullptr && ws.parts && ws.corr && ws.abar;
-  // ---- one GEMM of the encoder: activations [B*S rows][K] -> [B*S rows][N]
-  //  * images of 256 patches, batch >= 8, N % 256 == 0: gemm256p_kernel over image-aligned tiles (tile row b = rows
-  //    b*S + 1 .. b*S + 256 = the patch rows of image b) + gemm64_kernel over the B CLS rows (stride S);
-  //  * otherwise gemm64_kernel (<= 2047 rows) or gemm_kernel (128x128 tiles) over all rows, bias row looked up per row.
-  // Returns whether the image-aligned form ran (then a GELU epilogue has written its column sums itself).
-  auto gemm = [&](auto epic, const void* A, const void* Wt, int N, int K, const float* bias, const float* aux, void* out,
-                  int qcols, const float* corr, int cat, void* colmean = nullptr) -> bool {
+  // ---- one GEMM of the encoder: activations [B*S rows][K] -> [B*S rows][N], with the per-image bias rows that compensate
+  // the rounding of W (dW = the rounding residue x 4096; the mean row of the activation operand is in ws.abar, or comes
+  // from `nparts` partial column sums in ws.parts times `inv`)
+  //  * images of 256 patches, batch >= 8, N % 256 == 0: ONE gemm64_kernel launch for the 2 B latency-bound rows (the B CLS
+  //    rows, stride S, plain bias; the B mean rows against dW -> ws.corr), then gemm256p_kernel over image-aligned tiles
+  //    (tile row b = rows b*S + 1 .. b*S + 256 = the patch rows of image b) with ws.corr as its bias rows;
+  //  * otherwise a corr-only gemm64_kernel launch, then gemm64_kernel (<= 2047 rows) or gemm_kernel (128x128 tiles) over all rows, bias row
+  //    looked up per row.
+  // Returns whether the image-aligned form ran (then a GELU epilogue writes the mean row of its output itself).
+  auto gemm = [&](auto epic, const void* A, const void* Wt, const void* dW, int N, int K, const float* bias, const float* aux,
+                  void* out, int qcols, int cat, int nparts, float inv, void* colmean = nullptr) -> bool {
     constexpr int EPI = decltype(epic)::value;
     GemmArgs a{A, Wt, M, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
-    a.corr = corr;
     const bool fits32 = (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
     const bool aligned = P == HBM_ && N % HBN_ == 0 && M > G64_MAXM && K >= 128 && K % 64 == 0 && fits32;
-    pf.begin(cat, st);
+    pf.begin(CAT_COMP, st);
+    if (comp && nparts > 0)
+      hipLaunchKernelGGL((mean16_kernel<T>), dim3((K / 4 + 255) / 256, B), dim3(256), 0, st, ws.parts, nparts, inv,
+                         reinterpret_cast<T*>(ws.abar), K);
     if (aligned) {
+      GemmArgs c = a;                                  // the B CLS rows (+ the B mean rows -> ws.corr)
+      c.M = B; c.row0 = 0; c.row_step = S;
+      c.nb1 = ((B + SBM - 1) / SBM) * (N / SBN);
+      int nblocks = c.nb1;
+      if (comp) { c.abar2 = ws.abar; c.dW2 = dW; c.corr2 = ws.corr; c.M2 = B; nblocks *= 2; }
+      hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
+      pf.end(CAT_COMP, st);
       const int nbn = N / HBN_;
+      a.corr = comp ? ws.corr : nullptr;
       a.nbm = B; a.tile_row0 = 1; a.tile_stride = S; a.colmean = colmean;
-      if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), 131072, st, a);
-      else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), 131072, st, a);
-      const bool main_only = pf.mode == 1;             // "dominant kernel only": the bracket covers the 256x256 launch alone
-      if (main_only) pf.end(cat, st);
-      GemmArgs c = a;
-      c.M = B; c.row0 = 0; c.row_step = S; c.colmean = nullptr;
-      hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(((B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
-      if (!main_only) pf.end(cat, st);
+      const size_t lds = 131072 + (EPI == EPI_GELU ? 4096 : 0);
+      pf.begin(cat, st);
+      if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), lds, st, a);
+      else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), lds, st, a);
+      pf.end(cat, st);
       return true;
     }
+    if (comp) {                                        // the same gemm64_body<EPI_CORR> arithmetic as the fused launch above
+      GemmArgs c{ws.abar, dW, B, N, K, bias, nullptr, ws.corr, P, S, 0, 1.f};
+      hipLaunchKernelGGL((gemm64_kernel<Op, EPI_CORR>), dim3(((B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
+      a.corr = ws.corr;
+    }
+    pf.end(CAT_COMP, st);
+    pf.begin(cat, st);
     if (M <= G64_MAXM && fits32 && N % SBN == 0 && K % 64 == 0)
       hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(((M + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, a);
     else
       hipLaunchKernelGGL((gemm_kernel<Op, EPI>), dim3(((M + GBM - 1) / GBM) * (N / GBN)), dim3(256), gsm, st, a);
     pf.end(cat, st);
     return false;
-  };
-  // per-image bias row of the next GEMM from the column sums in ws.parts (2 halves per image, P rows in all)
-  // (ws.parts holds `nparts` partial sums per image and column, whose total times `inv` is the mean row)
-  auto corr_for = [&](const void* dW, const float* bias, int N, int K, int nparts, float inv) -> const float* {
-    if (!comp) return nullptr;
-    if (nparts > 0)
-      hipLaunchKernelGGL((mean16_kernel<T>), dim3((K / 4 + 255) / 256, B), dim3(256), 0, st, ws.parts, nparts, inv,
-                         reinterpret_cast<T*>(ws.abar), K);
-    if (K >= 2048)
-      hipLaunchKernelGGL((corr_kernel<Op, 16>), dim3((B + 31) / 32, N / 64), dim3(1024), 0, st, reinterpret_cast<const T*>(ws.abar),
-                         reinterpret_cast<const T*>(dW), bias, ws.corr, B, N, K);
-    else
-      hipLaunchKernelGGL((corr_kernel<Op, 8>), dim3((B + 31) / 32, N / 64), dim3(512), 0, st, reinterpret_cast<const T*>(ws.abar),
-                         reinterpret_cast<const T*>(dW), bias, ws.corr, B, N, K);
-    return ws.corr;
   };
   const int nchunk = (S + 15) / 16;
   auto layernorm = [&](const float* sc, const float* bi) {           // norm1 / norm2 (+ the column sums of the output)
@@ -1333,34 +1310,22 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     layernorm(L.ln1_s, L.ln1_b);
     pf.end(1, st);
     audit_of(ws.h, (size_t)M * E, 0);
-    pf.begin(CAT_COMP, st);
-    const float* cq = corr_for(L.dqkv, L.bqkv, 3 * E, E, nchunk, 1.f / (float)S);
-    pf.end(CAT_COMP, st);
-    gemm(EQ{}, ws.h, L.wqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, cq, 2);
+    gemm(EQ{}, ws.h, L.wqkv, L.dqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, 2, nchunk, 1.f / (float)S);
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
     pf.begin(3, st);
     hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr);
     pf.end(3, st);
     audit_of(ws.h, (size_t)M * E, 2);
-    pf.begin(CAT_COMP, st);
-    const float* co = corr_for(L.dwo, L.bo, E, E, 0, 0.f);                 // the attention kernel wrote the mean row itself
-    pf.end(CAT_COMP, st);
-    gemm(ER{}, ws.h, L.wo, E, E, L.bo, L.ls1, ws.x, 0, co, 4);
+    gemm(ER{}, ws.h, L.wo, L.dwo, E, E, L.bo, L.ls1, ws.x, 0, 4, 0, 0.f);           // the attention kernel wrote the mean row itself
     pf.begin(1, st);
     layernorm(L.ln2_s, L.ln2_b);
     pf.end(1, st);
     audit_of(ws.h, (size_t)M * E, 0);
-    pf.begin(CAT_COMP, st);
-    const float* c1 = corr_for(L.dw1, L.b1, F, E, nchunk, 1.f / (float)S);
-    pf.end(CAT_COMP, st);
-    const bool summed = gemm(EG{}, ws.h, L.w1, F, E, L.b1, nullptr, ws.g, 0, c1, 5, comp ? ws.abar : nullptr);
+    const bool summed = gemm(EG{}, ws.h, L.w1, L.dw1, F, E, L.b1, nullptr, ws.g, 0, 5, nchunk, 1.f / (float)S, comp ? ws.abar : nullptr);
     audit_of(ws.g, (size_t)M * F, 3);
-    pf.begin(CAT_COMP, st);
-    if (!summed) colsum_of(ws.g, F);
-    const float* c2 = corr_for(L.dw2, L.b2, E, F, summed ? 0 : 2, 1.f / (float)P);   // aligned tiles: the epilogue wrote the mean row
-    pf.end(CAT_COMP, st);
-    gemm(ER{}, ws.g, L.w2, E, F, L.b2, L.ls2, ws.x, 0, c2, 6);
+    if (!summed) colsum_of(ws.g, F);                                                  // aligned tiles: the GELU epilogue wrote the mean row
+    gemm(ER{}, ws.g, L.w2, L.dw2, E, F, L.b2, L.ls2, ws.x, 0, 6, summed ? 0 : 2, 1.f / (float)P);
   }
   pf.begin(1, st);
   if (keep_cls)

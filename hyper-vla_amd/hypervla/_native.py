@@ -21,7 +21,7 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
            "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit", "hvla_train_accumulate"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy",
-              "weight_rounding_compensation"]
+              "small_row_gemms"]      # mean rows + the 2 B latency-bound rows per GEMM: CLS rows and weight-rounding compensation rows
 
 
 class hvla_config(C.Structure):

@@ -226,7 +226,8 @@ int hvla_t5_encode(hvla_ctx* ctx, const int64_t* input_ids, const int64_t* atten
 #define HVLA_PROF_FC1 5     /* encoder fc1 GEMM (+erf GELU)             */
 #define HVLA_PROF_FC2 6     /* encoder fc2 GEMM (+residual)             */
 #define HVLA_PROF_POLICY 7  /* generated-policy megakernel              */
-#define HVLA_PROF_COMP 8    /* encoder: column sums + per-image bias rows that compensate the weight rounding */
+#define HVLA_PROF_COMP 8    /* encoder: the small launches in front of each big GEMM -- mean rows of its activation operand and the 2 B
+                               latency-bound rows (B CLS rows + B rows that compensate the weight rounding)                      */
 #define HVLA_PROF_N 9
 int hvla_profile(hvla_ctx* ctx, int32_t mode);
 int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches);
