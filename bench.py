@@ -26,6 +26,7 @@ for p in (os.path.join(ROOT, "hyper-vla_amd"), ROOT):
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
+PMC_ROUND = "r2"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
 PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
@@ -304,8 +305,8 @@ def main():
         import csv                      # committed rocprofv3 --pmc passes of this same command (profiles/)
         vals = {}
         for nm in ("fetch", "write"):
-            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_pmc_{nm}_size_by_kernel.csv"))):
-                if "gemm256p_kernel<hvla::OpF16, 2" in row["kernel"]:
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_{nm}_size_by_kernel.csv"))):
+                if "gemm256p_kernel<hvla::OpF16, 2" in row["kernel"]:      # <Op, EPI_GELU, ...>: the fc1 launch
                     vals[nm] = float(row["mean"]) * 1024.0
         if B == 256 and a.enc_dtype == "f16" and a.encoder == "base" and a.streams == 1 and len(vals) == 2:
             traffic = int(2 * vals["fetch"] + vals["write"])
@@ -330,9 +331,9 @@ def main():
                    "batch_per_gpu": B, "global_batch": world * B, "encoder": "DINOv2-base (reference parity, E=768)" if a.encoder == "base" else "DINOv2-small (E=384)",
                    "parallelism": f"episode-dp{world} (no collectives)",
                    "encoder_operands": a.enc_dtype + " (+ per-image first-order compensation of the weight rounding, "
-                                       "kernel_ms_per_step.weight_rounding_compensation)",
+                                       "kernel_ms_per_step.small_row_gemms)",
                    "policy_operands": "split-bf16 (bf16x3)",
-                   "launch": "hipGraph replay" if a.graph else f"eager (about {140 if B * g.seq > 2047 else 90} launches per step)",
+                   "launch": "hipGraph replay" if a.graph else f"eager (about {13 * g.enc_layers + 6} launches per step)",
                    "streams": a.streams,
                    "ensemble": "device-side un-normalise + temporal ensemble (history = horizon) inside the step"
                                if ens is not None else "not in the step"},

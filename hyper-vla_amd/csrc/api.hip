@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "layout.h"
+#include "pack.h"
 #include "t5.h"
 #include "train.h"
 
@@ -32,24 +33,9 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-inline uint16_t f2bf(float f) {          // round-to-nearest-even, NaN preserved
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-inline float bf2f(uint16_t h) {
-  uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-inline uint16_t f2h(float f) {
-  _Float16 h = (_Float16)f;
-  uint16_t u;
-  memcpy(&u, &h, 2);
-  return u;
-}
+using hvla::pack::bf2f;
+using hvla::pack::f2bf;
+using hvla::pack::f2h;
 
 }  // namespace
 
@@ -250,14 +236,12 @@ int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
   }
   // ------------------------------------------------------------ W_cat / b_cat in packed order
   const PolicyLayout& pl = ctx->lay.pl;
-  const int Gtot = pl.Gm + pl.Gv, ntiles = Gtot / 32, KS = C / 16;
+  const int Gtot = pl.Gm + pl.Gv;
   auto leaves = generated_leaves(g);
   std::vector<const float*> lk(leaves.size()), lb(leaves.size());
-  std::vector<int32_t> leaf_of(pl.G);
   for (size_t i = 0; i < leaves.size(); ++i) {
     lk[i] = get("output_head_" + leaves[i].flat + "/kernel", (int64_t)C * leaves[i].size);
     lb[i] = get("output_head_" + leaves[i].flat + "/bias", leaves[i].size);
-    for (int64_t j = 0; j < leaves[i].size; ++j) leaf_of[leaves[i].offset + j] = (int32_t)i;
   }
   // ------------------------------------------------------------ DINOv2 (shared leaves, flat vectors)
   const std::string ep = "encoder_image_encoder_";
@@ -293,36 +277,11 @@ int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
 
   // ---- pack W_cat^T fragments (layout.h): tile pt, k-step ks, lane (rho = l & 31, hk = l >> 5), j
   {
-    std::vector<uint16_t> hi((size_t)ntiles * KS * 512), lo(hi.size());
-    std::vector<float> bc(Gtot, 0.f);
-    const int32_t* perm = ctx->lay.perm.data();
-    for (int pos = 0; pos < Gtot; ++pos)
-      if (perm[pos] >= 0) {
-        const int ref = perm[pos], li = leaf_of[ref];
-        bc[pos] = lb[li][ref - leaves[li].offset];
-      }
-    for (int pt = 0; pt < ntiles; ++pt)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int rho = lane & 31, hk = lane >> 5;
-        const int tau = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
-        const int ref = perm[pt * 32 + tau];
-        const float* col = nullptr;
-        int64_t n_leaf = 0;
-        if (ref >= 0) {
-          const int li = leaf_of[ref];
-          col = lk[li] + (ref - leaves[li].offset);
-          n_leaf = leaves[li].size;
-        }
-        for (int ks = 0; ks < KS; ++ks)
-          for (int j = 0; j < 8; ++j) {
-            const int k = 16 * ks + 8 * hk + j;
-            const float w = col ? col[(int64_t)k * n_leaf] : 0.f;
-            const uint16_t h = f2bf(w);
-            const size_t o = ((size_t)(pt * KS + ks) * 64 + lane) * 8 + j;
-            hi[o] = h;
-            lo[o] = f2bf(w - bf2f(h));
-          }
-      }
+    std::vector<uint16_t> hi, lo;
+    std::vector<float> bc;
+    for (size_t i = 0; i < leaves.size(); ++i)
+      if (!lk[i] || !lb[i]) FAIL(ctx, HVLA_E_WEIGHTS, "output head %s missing", leaves[i].flat.c_str());
+    pack::pack_wcat(ctx->lay, leaves, lk, lb, C, hi, lo, bc);
     HIPCHK(ctx, ctx->wcat_hi.alloc(hi.size() * 2));
     HIPCHK(ctx, ctx->wcat_lo.alloc(lo.size() * 2));
     HIPCHK(ctx, ctx->bcat.alloc(bc.size() * 4));
@@ -351,12 +310,7 @@ int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
     const int Kp1 = Kp / 2;
     mark16((size_t)E * Kp);
     markf(E);
-    auto back = [&](uint16_t h) -> float {
-      if (bf) return bf2f(h);
-      _Float16 x;
-      memcpy(&x, &h, 2);
-      return (float)x;
-    };
+    auto back = [&](uint16_t h) -> float { return pack::from16(h, bf); };
     for (int nn = 0; nn < E; ++nn) {
       double bacc = e_pb[nn];
       for (int k = 0; k < Kp1; ++k) {
@@ -380,15 +334,7 @@ int hvla_load_weights(hvla_ctx* ctx, const hvla_tensor_desc* t, int32_t n) {
     markf(E); memcpy(&wf[offf.back()], e_lnb, E * 4);
     // flax [K][N] -> [N][K] 16-bit, and what the rounding dropped (x 4096: stays in the normal range of fp16) for the
     // per-image compensation of the encoder GEMMs (encoder.hip corr_kernel)
-    auto tr = [&](const float* src, int K, int N, size_t dst) {
-      for (int nn = 0; nn < N; ++nn)
-        for (int k = 0; k < K; ++k) {
-          const float wv = src[(size_t)k * N + nn];
-          const uint16_t h = cv(wv);
-          w16[dst + (size_t)nn * K + k] = h;
-          d16[dst + (size_t)nn * K + k] = cv((wv - back(h)) * 4096.f);
-        }
-    };
+    auto tr = [&](const float* src, int K, int N, size_t dst) { pack::pack_matrix_t(src, K, N, bf, &w16[dst], &d16[dst]); };
     for (int i = 0; i < g.enc_layers; ++i) {
       const LSrc& s = ls[i];
       mark16((size_t)3 * E * E);

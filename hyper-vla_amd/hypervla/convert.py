@@ -342,8 +342,18 @@ def convert_checkpoint(src_dir: str, dst_dir: str, step: int, ema: Optional[floa
     os.makedirs(dst_dir, exist_ok=True)
     out = os.path.join(dst_dir, f"params_{step}.npz")
     np.savez(out, **params)
-    for name in ("config.json", "dataset_statistics.json"):
+    for name in ("dataset_statistics.json", "example_batch.msgpack"):
         sp = os.path.join(src_dir, name)
         if os.path.exists(sp) and os.path.abspath(src_dir) != os.path.abspath(dst_dir):
             shutil.copyfile(sp, os.path.join(dst_dir, name))
+    # the reference keeps HF's 37 x 37 DINOv2 position table and resizes it inside every forward pass; here it is baked to
+    # the run-time grid once.  The config says so: FineTuner refuses to train a baked table unless told to
+    flat = flatten_tree(tree)
+    pos = [v for k, v in flat.items() if k.endswith("embeddings_position_embeddings")]
+    rows = int(np.asarray(pos[0]).size // g.enc_dim) - 1 if pos else g.patches
+    if rows != g.patches:
+        n = int(round(np.sqrt(rows)))
+        config["position_embeddings_baked_from"] = [n, n]
+    with open(os.path.join(dst_dir, "config.json"), "w") as f:
+        json.dump(config, f)
     return out

@@ -94,6 +94,29 @@ def test_convert_checkpoint_directory_round_trip(fake_jax, tmp_path):
     assert (dst / "config.json").exists() and (dst / "dataset_statistics.json").exists()
 
 
+def test_converter_records_a_baked_position_table(fake_jax, tmp_path):
+    """A checkpoint that carries HF's un-resized position table (the reference resizes it in every forward pass,
+    SURVEY App. A) is baked to the run-time grid and the converted config says so; example_batch.msgpack is carried over."""
+    import json
+    g = TINY                                                    # 4 x 4 patches
+    P = syn.synthetic_params(g)
+    key = "encoder_image_encoder_embeddings_position_embeddings"
+    big = np.random.default_rng(0).standard_normal((1, 1 + 9 * 9, g.enc_dim)).astype(np.float32)
+    tree = _nest({k: (big.reshape(-1) if k == key else v) for k, v in P.items()})
+    src, dst = tmp_path / "run", tmp_path / "out"
+    src.mkdir()
+    (src / "config.json").write_text(json.dumps(default_config(g)))
+    (src / "example_batch.msgpack").write_bytes(cv.msgpack_serialize({"task": {"language_instruction": {"input_ids": np.zeros((1, 8), np.int64)}}}))
+    out = cv.convert_checkpoint(str(src), str(dst), 3, tree=tree)
+    with np.load(out) as z:
+        np.testing.assert_allclose(z[key].reshape(1, 17, g.enc_dim), cv.bake_position_embeddings(big, 4))
+    assert json.loads((dst / "config.json").read_text())["position_embeddings_baked_from"] == [9, 9]
+    assert cv.load_example_batch(str(dst))["task"]["language_instruction"]["input_ids"].shape == (1, 8)
+    # a table that already has the run-time grid is not marked
+    out2 = cv.convert_checkpoint(str(src), str(tmp_path / "out2"), 3, tree=_nest(P))
+    assert "position_embeddings_baked_from" not in json.loads((tmp_path / "out2" / "config.json").read_text())
+
+
 def test_tree_errors_name_the_problem():
     g = TINY
     P = syn.synthetic_params(g)
@@ -174,7 +197,7 @@ def test_example_batch_msgpack_without_flax(tmp_path):
     reference adds when the file lacks it (:190-192)."""
     from hypervla.convert import load_example_batch, msgpack_restore, msgpack_serialize
     wire = bytes.fromhex("81" "a161"                      # map of 1: "a"
-                         "c7" "18" "01"                   # ext8, 24 payload bytes, type 1 (ndarray)
+                         "c7" "17" "01"                   # ext8, 23 payload bytes, type 1 (ndarray)
                          "93" "91" "03"                   # (shape = [3],
                          "a5" "696e743332"                #  "int32",
                          "c4" "0c" "010000000200000003000000")   # bin8, 12 bytes)
@@ -194,5 +217,5 @@ def test_example_batch_msgpack_without_flax(tmp_path):
     assert back["task"]["language_instruction"]["token_embedding"].shape == (2, 32, 768)
     assert load_example_batch(str(tmp_path / "nowhere")) is None
     # bfloat16 leaves (not a numpy dtype) come back as float32
-    bf = msgpack_restore(bytes.fromhex("81a162" "c7" "0f" "01" "93" "91" "01" "a8" + "bfloat16".encode().hex() + "c4" "02" "803f"))
+    bf = msgpack_restore(bytes.fromhex("81a162" "c7" "10" "01" "93" "91" "01" "a8" + "bfloat16".encode().hex() + "c4" "02" "803f"))
     assert bf["b"].dtype == np.float32 and bf["b"].tolist() == [1.0]

@@ -308,7 +308,7 @@ def test_config5_per_gpu_step_at_full_geometry():
     ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
     batch = syn.synthetic_action_batch(B, g)
     ft = FineTuner(model, B, train_encoder=True)
-    assert ft.n - ft.n_hyper > 86_000_000                                   # the DINOv2-base leaves are in the vector
+    assert ft.n - ft.n_hyper > 85_000_000                                   # the DINOv2-base leaves (16 x 16 position table) are in the vector
     loss = ft.forward_backward(ins, st, im, batch).clone()
     assert torch.isfinite(loss).all() and torch.isfinite(ft.grads).all()
     gfull = ft.grads.double().clone()
@@ -330,9 +330,25 @@ def test_config5_per_gpu_step_at_full_geometry():
     scale = float(gfull.abs().max())
     assert float((acc - gfull).abs().max()) <= 2e-3 * scale, (float((acc - gfull).abs().max()), scale)
     before = ft.params.clone()
-    ft.apply()
+    ft.apply(lr=1e-4, base_lr=1e-5)                  # (the schedules themselves start their warm-up at 0)
     moved = (ft.params - before).abs()
     assert float(moved[:ft.n_hyper].max()) > 0 and float(moved[ft.n_hyper:].max()) > 0
+
+
+def test_training_a_baked_position_table_must_be_asked_for():
+    """The converter bakes HF's 37 x 37 DINOv2 position table to the run-time grid; the reference trains the original table
+    through interpolate_pos_encoding, so FineTuner(train_encoder=True) refuses such a checkpoint unless told to go ahead."""
+    from hypervla import synthetic as syn
+    from hypervla.config import MID, default_config
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner
+    cfg = default_config(MID)
+    cfg["position_embeddings_baked_from"] = [37, 37]
+    m = HyperVLA(cfg, syn.synthetic_params(MID), None, None, max_batch=2)
+    FineTuner(m, 2)                                             # frozen encoder: fine
+    with pytest.raises(ValueError, match="baked"):
+        FineTuner(m, 2, train_encoder=True)
+    FineTuner(m, 2, train_encoder=True, accept_baked_position_table=True)
 
 
 def test_encoder_training_reduces_loss():
