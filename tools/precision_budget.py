@@ -43,7 +43,7 @@ def rounder(kind):
     return lambda t: t
 
 
-def encoder(hp, g, enc_shapes, images_u8, sites, kind="f16", layer_kinds=None, layers_on=None, corr=None, collect=None):
+def encoder(hp, g, enc_shapes, images_u8, sites, kind="f16", layer_kinds=None, layers_on=None, corr=None, collect=None, fold=False):
     """DINOv2 forward in float64 with the listed operand sites rounded (oracle/hvla_ref_np.py::dinov2 restated on torch
     for speed)."""
     E, H = g.enc_dim, g.enc_heads
@@ -77,16 +77,35 @@ def encoder(hp, g, enc_shapes, images_u8, sites, kind="f16", layer_kinds=None, l
             y = y + corr[key] @ (W - Wr(W))
         return y
 
+    def ln_mm(x, s, b, W, bias, Wr, Xr):
+        """LayerNorm folded into the GEMM that consumes it (study "foldln"): the 16-bit operand is x itself, the LN scale
+        is folded into W, mean / rstd come in as a rank-1 correction of the f32 accumulator, the weight rounding is
+        compensated per image with the mean row of x:  r (x16 W'16 + xbar dW' - mu colsum(W')) + (b + beta W)."""
+        m = x.mean(-1, keepdim=True)
+        v = (x * x).mean(-1, keepdim=True) - m * m
+        r = torch.rsqrt(v.clamp_min(0) + 1e-6)
+        Wp = s[:, None] * W
+        W16 = Wr(Wp)
+        x16 = Xr(x)
+        acc = x16 @ W16 + x16[:, 1:].mean(1, keepdim=True) @ (Wp - W16)
+        return r * (acc - m * Wp.sum(0)) + (bias + b @ W)
+
     for i in range(g.enc_layers):
         k_i = layer_kinds[i] if layer_kinds else kind
         rd = rounder(k_i)
         act = sites if layers_on is None or i in layers_on else set()
         R = {s: (rd if (s in act or (s[0] == "w" and "w" in act)) else (lambda t: t)) for s in "h w wq wo w1 w2 qkv p o g".split()}
         L = ("encoder", "layer", str(i))
+        if fold:
+            Wqkv = torch.cat([get(L + ("attention", "attention", n_, "kernel")) for n_ in ("query", "key", "value")], 1)
+            bqkv = torch.cat([get(L + ("attention", "attention", n_, "bias")) for n_ in ("query", "key", "value")], 0)
+            qkv_ = ln_mm(x, get(L + ("norm1", "scale")), get(L + ("norm1", "bias")), Wqkv, bqkv, R["wq"], R["h"])
         h = R["h"](ln(x, get(L + ("norm1", "scale")), get(L + ("norm1", "bias"))))
         q = mm(h, get(L + ("attention", "attention", "query", "kernel")), R["wq"], (i, "h1")) + get(L + ("attention", "attention", "query", "bias"))
         k = mm(h, get(L + ("attention", "attention", "key", "kernel")), R["wq"], (i, "h1")) + get(L + ("attention", "attention", "key", "bias"))
         v = mm(h, get(L + ("attention", "attention", "value", "kernel")), R["wq"], (i, "h1")) + get(L + ("attention", "attention", "value", "bias"))
+        if fold:
+            q, k, v = qkv_[..., :E], qkv_[..., E:2 * E], qkv_[..., 2 * E:]
         q = R["qkv"](q * (np.log2(np.e) / 8.0)) / (np.log2(np.e) / 8.0) * (1.0 / 8.0) * 8.0   # stored pre-scaled by log2e/8
         k, v = R["qkv"](k), R["qkv"](v)
         q, k, v = (t.reshape(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
@@ -99,6 +118,8 @@ def encoder(hp, g, enc_shapes, images_u8, sites, kind="f16", layer_kinds=None, l
         x = x + o * get(L + ("layer_scale1", "lambda1"))
         h = R["h"](ln(x, get(L + ("norm2", "scale")), get(L + ("norm2", "bias"))))
         a = mm(h, get(L + ("mlp", "fc1", "kernel")), R["w1"], (i, "h2")) + get(L + ("mlp", "fc1", "bias"))
+        if fold:
+            a = ln_mm(x, get(L + ("norm2", "scale")), get(L + ("norm2", "bias")), get(L + ("mlp", "fc1", "kernel")), get(L + ("mlp", "fc1", "bias")), R["w1"], R["h"])
         stats.setdefault("fc1_absmax", []).append(float(a.abs().max()))
         a = R["g"](0.5 * a * (1.0 + torch.erf(a / np.sqrt(2.0))))
         stats.setdefault("g_absmax", []).append(float(a.abs().max()))
@@ -114,7 +135,7 @@ def main():
     ap.add_argument("--style", default="synthetic")
     ap.add_argument("--geometry", default="full")
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--study", default="sites", choices=["sites", "weights", "bias"])
+    ap.add_argument("--study", default="sites", choices=["sites", "weights", "bias", "foldln"])
     ap.add_argument("--images", default="noise", choices=["noise", "structured"])
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -148,6 +169,15 @@ def main():
             d = np.abs(act[..., :6] - act0[..., :6])
             dt = (tok - tok0).numpy()
             print(f"{name:24s} action MAE {d.mean():.2e} max {d.max():.2e} p99 {np.quantile(d, 0.99):.2e} | logit max {np.abs(logit - logit0).max():.2e} | "
+                  f"token rms {np.sqrt((dt * dt).mean()):.2e} max {np.abs(dt).max():.2e}", flush=True)
+        return
+    if a.study == "foldln":
+        for name, kw in (("f16 + per-image corr (LN pass)", dict(corr="dynamic")), ("f16, LN folded into QKV / fc1", dict(corr="dynamic", fold=True))):
+            tok, _ = encoder(hp, g, enc_shapes, im[:, 0], allsites, "f16", **kw)
+            act, logit, _ = onp.policy(bp, g, tok.numpy())
+            d = np.abs(act[..., :6] - act0[..., :6])
+            dt = (tok - tok0).numpy()
+            print(f"{name:32s} action MAE {d.mean():.2e} max {d.max():.2e} p99 {np.quantile(d, 0.99):.2e} | logit max {np.abs(logit - logit0).max():.2e} | "
                   f"token rms {np.sqrt((dt * dt).mean()):.2e} max {np.abs(dt).max():.2e}", flush=True)
         return
     if a.study == "weights":
