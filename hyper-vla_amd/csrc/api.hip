@@ -39,13 +39,6 @@ using hvla::pack::f2h;
 
 }  // namespace
 
-// floats of column-sum scratch per image: two halves of the widest activation row (GELU outputs), or one partial per
-// 16-row chunk of a LayerNorm output
-static size_t parts_per_image(const Geom& g) {
-  const size_t a = (size_t)2 * (g.enc_mlp > g.E ? g.enc_mlp : g.E), b = (size_t)((g.S() + 15) / 16) * g.E;
-  return a > b ? a : b;
-}
-
 struct hvla_weights {
   int B = 0;
   DevBuf wh, wl, vf, ctx, ring, count;
@@ -66,12 +59,16 @@ struct hvla_ctx {
   DevBuf enc16, encd16, encf32;  // encoder matrices (16-bit), their rounding residues x 4096 (16-bit) and vectors (f32)
   EncWeights encw{};
   // workspaces (sized for cfg.max_batch)
-  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_parts, ws_corr, ws_abar, tokens, flags;
+  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_corr, ws_abar, tokens, flags;
   Profiler prof;
   // cfg.streams == 2: helper stream and fork / join events of hvla_step
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_bucket[3] = {nullptr, nullptr, nullptr};   // hvla_train_step: gradient buckets final (created on first use)
+  bool bucket_recorded[3] = {false, false, false};
   ~hvla_ctx() {
+    for (hipEvent_t e : ev_bucket)
+      if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (side) (void)hipStreamDestroy(side);
@@ -152,7 +149,7 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   A(ctx->ctx_hi, Bm * g.C * 2); A(ctx->ctx_lo, Bm * g.C * 2); A(ctx->ctx_f32, Bm * g.C * 4);
   A(ctx->ws_x, Bm * S * E * 4); A(ctx->ws_h, Bm * S * E * 2); A(ctx->ws_qkv, Bm * S * 3 * E * 2);
   A(ctx->ws_g, gbytes); A(ctx->tokens, Bm * P * E * 4); A(ctx->flags, 64 * sizeof(int));
-  A(ctx->ws_parts, Bm * parts_per_image(g) * 4); A(ctx->ws_corr, Bm * (F > 3 * E ? F : 3 * E) * 4);
+  A(ctx->ws_corr, Bm * (F > 3 * E ? F : 3 * E) * 4);
   A(ctx->ws_abar, Bm * (F > E ? F : E) * 2);
   if (e != hipSuccess) return HVLA_E_ARENA_FULL;
   if (c->streams == 2) {
@@ -446,7 +443,7 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
   const size_t S = g.S(), E = g.E, F = g.enc_mlp, rows = (size_t)b0 * S;
   EncWorkspace ws{ctx->ws_x.as<float>() + rows * E, static_cast<char*>(ctx->ws_h.p) + rows * E * 2,
                   static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + rows * F * 2,
-                  ctx->ws_parts.as<float>() + (size_t)b0 * parts_per_image(g), ctx->ws_corr.as<float>() + (size_t)b0 * (F > 3 * E ? F : 3 * E),
+                  ctx->ws_corr.as<float>() + (size_t)b0 * (F > 3 * E ? F : 3 * E),
                   static_cast<char*>(ctx->ws_abar.p) + (size_t)b0 * (F > E ? F : E) * 2};
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
@@ -482,7 +479,7 @@ int hvla_encode_audit(hvla_ctx* ctx, const uint8_t* images, int32_t B, float* ma
   HIPCHK(ctx, hipMemsetAsync(slots, 0, 8 * sizeof(uint32_t), st));
   const Geom& g = ctx->g;
   const size_t F = g.enc_mlp, E = g.E;
-  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p, ctx->ws_parts.as<float>(), ctx->ws_corr.as<float>(), ctx->ws_abar.p};
+  EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p, ctx->ws_corr.as<float>(), ctx->ws_abar.p};
   (void)F; (void)E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images, ctx->tokens.as<float>(), B, st, nullptr, false, slots));
   uint32_t h[8];
@@ -608,7 +605,29 @@ int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* t
   const TrainLayout L = make_train_layout(ctx->g);
   TrainInputs in{tok, mask, cls, tokens, images, target, tmask, amask};
   const TrainHyper hp = to_hp(hy);
-  HIPCHK(ctx, train_step(ctx->g, L, to_tb(buf), in, B, hp, reinterpret_cast<hipStream_t>(stream)));
+  for (hipEvent_t& e : ctx->ev_bucket)
+    if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(ctx, train_step(ctx->g, L, to_tb(buf), in, B, hp, reinterpret_cast<hipStream_t>(stream), hp.forward_only ? nullptr : ctx->ev_bucket));
+  ctx->bucket_recorded[0] = !hp.forward_only && images != nullptr;
+  ctx->bucket_recorded[1] = ctx->bucket_recorded[2] = !hp.forward_only;
+  return HVLA_OK;
+}
+
+int hvla_train_bucket_ranges(hvla_ctx* ctx, int32_t train_encoder, int64_t out[6]) {
+  if (!ctx || !out) return HVLA_E_STATE;
+  const TrainLayout L = make_train_layout(ctx->g);
+  out[0] = L.total; out[1] = train_encoder ? L.enc_total : 0;     // the shared DINOv2 leaves
+  out[2] = L.wcat; out[3] = L.total - L.wcat;                     // the output heads (W_cat, b_cat)
+  out[4] = 0; out[5] = L.wcat;                                    // the context encoder
+  return HVLA_OK;
+}
+
+int hvla_train_wait_bucket(hvla_ctx* ctx, int32_t bucket, void* stream) {
+  if (!ctx) return HVLA_E_STATE;
+  if (bucket < 0 || bucket > 2) FAIL(ctx, HVLA_E_SHAPE, "bucket %d outside [0, 2]", bucket);
+  if (!ctx->bucket_recorded[bucket]) FAIL(ctx, HVLA_E_STATE, "bucket %d was not produced by the last hvla_train_step", bucket);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), ctx->ev_bucket[bucket], 0));
   return HVLA_OK;
 }
 

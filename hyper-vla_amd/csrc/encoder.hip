@@ -19,7 +19,7 @@
 //   mean rows / corr   first-order compensation of the WEIGHT rounding: A W = A W16 + A dW with
 //                      dW = W - W16; A dW is replaced by (per-image mean row of A) dW, a [B, N] table (gemm64_kernel's
 //                      second problem) that the epilogues add instead of the bias.  The mean rows come out of the kernels
-//                      that write A: layernorm_cs_kernel, attention_kernel, the GELU epilogue.  Rounding a shared weight perturbs every token of an image the same way,
+//                      that write A: layernorm_img_kernel, attention_kernel, the GELU epilogue.  Rounding a shared weight perturbs every token of an image the same way,
 //                      which the generated policy (it pools the 256 tokens) feels about sqrt(257) times more than the
 //                      independent rounding of activations; the mean row carries most of that coherent part.
 //   layernorm_kernel   f32 rows -> 16-bit rows (eps 1e-6), one wavefront per row; final variant drops the
@@ -120,7 +120,7 @@ __device__ __forceinline__ int wperm(int rho) { return (rho & ~63) + 4 * (rho & 
 // predicated block, which also waits for the previous STORE: 32 serialised store round trips per wave, 6.5 us per tile).
 // CS (GELU, FULL only): also returns in cs this lane's sums over its rows of the ROUNDED outputs of its four columns,
 // accumulated in the operand type itself (fp16: two v_pk_add_f16 per row instead of four converts and four adds; 32 values
-// per lane, and the mean row only needs a few per cent: colsum_kernel restates exactly this arithmetic).
+// per lane, and the mean row only needs a few per cent: colmean_kernel restates exactly this arithmetic).
 template <typename Op, int EPI, int MT, bool FULL, bool ROWBIAS, bool CS = false>
 __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
                                                         int fr, int fq, const f32x4* pre_b4, const f32x4* pre_l4,
@@ -183,7 +183,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
           typename Op::x4 o;
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = (T)t[c][r];
-          if constexpr (CS) *cs += o;                      // rows in ascending order: the order colsum_kernel restates
+          if constexpr (CS) *cs += o;                      // rows in ascending order: the order colmean_kernel restates
           *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]) = o;
         } else if constexpr (EPI == EPI_RES) {
           f32x4 x = xin[u][r];
@@ -741,22 +741,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
-// LayerNorm in front of a GEMM (norm1 / norm2), with the column sums of its output that the GEMM's weight-rounding
-// compensation needs (the corr rows of gemm64_kernel): workgroup (c, b) = rows [16 c, 16 c + 16) of image b, wave w takes rows 4 w .. 4 w + 3
-// of them one after the other (the next row's loads in flight), each lane keeps the running sums of its columns, the four
-// waves are combined through LDS in wave order: parts[b][c][E].  Chunks are relative to the image, so the sums do not depend on where the image sits in the
-// batch.  E % 4 == 0, E <= 1024.
+// LayerNorm in front of a GEMM (norm1 / norm2), with the mean row of its output that the GEMM's weight-rounding
+// compensation needs (the corr rows of gemm64_kernel).  ONE workgroup of 16 waves per image: wave w normalises rows
+// w, w + 16, w + 32, ... one after the other (the next row's loads in flight under this row's arithmetic), each lane keeps
+// the running f32 sums of its columns, and the 16 waves are combined through LDS in wave order -- the mean row abar[b] comes
+// out of the same launch (no partial sums in memory, no second kernel), and the order of the additions depends on nothing
+// but the image.  A batch of 256 images is exactly one workgroup per CU.  E % 4 == 0, E <= 1024.
+constexpr int LNW = 16;
 template <typename Op>
-__global__ __launch_bounds__(256) void layernorm_cs_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
-                                                           const float* __restrict__ scale, const float* __restrict__ bias,
-                                                           float* __restrict__ parts, int S, int E) {
+__global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
+                                                                 const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                 typename Op::elem* __restrict__ abar, int S, int E) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [4][E / 4]
-  const int b = blockIdx.y, c = blockIdx.x, nchunk = gridDim.x;
+  f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [LNW][E / 4]
+  const int b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n4 = E / 4;
-  const int r0 = 16 * c + 4 * wave;                                  // this wave's rows r0 .. r0 + 3 of the image
-  f32x4 cs[4], cur[4], nxt[4];
+  f32x4 cs[4], cur[4], nxt[4], s4[4], b4[4];
   auto load = [&](f32x4 (&v)[4], int row) {
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((size_t)b * S + (row < S ? row : S - 1)) * E);
 #pragma unroll
@@ -766,12 +767,15 @@ __global__ __launch_bounds__(256) void layernorm_cs_kernel(const float* __restri
     }
   };
 #pragma unroll
-  for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  load(cur, r0);
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = r0 + rr;
-    if (row >= S) break;                                             // wave-uniform
-    if (rr + 1 < 4) load(nxt, row + 1);                              // the next row is in flight under this row's arithmetic
+  for (int i = 0; i < 4; ++i) {
+    const int col = lane + 64 * i;
+    cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s4[i] = col < n4 ? reinterpret_cast<const f32x4*>(scale)[col] : cs[i];
+    b4[i] = col < n4 ? reinterpret_cast<const f32x4*>(bias)[col] : cs[i];
+  }
+  load(cur, wave);
+  for (int row = wave; row < S; row += LNW) {                        // wave-uniform
+    load(nxt, row + LNW);
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
@@ -797,12 +801,11 @@ __global__ __launch_bounds__(256) void layernorm_cs_kernel(const float* __restri
     for (int i = 0; i < 4; ++i) {
       const int col = lane + 64 * i;
       if (col < n4) {
-        const f32x4 s4 = reinterpret_cast<const f32x4*>(scale)[col], b4 = reinterpret_cast<const f32x4*>(bias)[col];
         f32x4 y;
         typename Op::x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          y[j] = (cur[i][j] - mean) * rstd * s4[j] + b4[j];
+          y[j] = (cur[i][j] - mean) * rstd * s4[i][j] + b4[i][j];
           o[j] = (typename Op::elem)y[j];
         }
         cs[i] += y;
@@ -812,6 +815,7 @@ __global__ __launch_bounds__(256) void layernorm_cs_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
   }
+  if (!abar) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     if (lane + 64 * i < n4) red[wave * n4 + lane + 64 * i] = cs[i];
@@ -819,8 +823,12 @@ __global__ __launch_bounds__(256) void layernorm_cs_kernel(const float* __restri
   if ((int)threadIdx.x < n4) {
     f32x4 t = red[threadIdx.x];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) t += red[w * n4 + threadIdx.x];
-    reinterpret_cast<f32x4*>(parts + ((size_t)b * nchunk + c) * E)[threadIdx.x] = t;
+    for (int w = 1; w < LNW; ++w) t += red[w * n4 + threadIdx.x];
+    const float inv = 1.f / (float)S;
+    typename Op::x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (typename Op::elem)(t[j] * inv);
+    reinterpret_cast<typename Op::x4*>(abar + (size_t)b * E)[threadIdx.x] = o;
   }
 }
 
@@ -1094,17 +1102,19 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 // the missing term A (W - W16) is approximated per image by  abar_b (W - W16),  abar_b = the mean over the image's patch
 // rows of A: a [B, N] table added by the epilogue in place of the bias.
 //
-// colsum_kernel: column sums of a 16-bit activation matrix over the P patch rows of every image (the CLS row is left out:
-// the table only needs the mean to a few per cent), as two halves so that gemm256p_kernel's GELU epilogue can produce the
+// colmean_kernel: mean row of a 16-bit activation matrix over the P patch rows of every image (the CLS row is left out:
+// the table only needs the mean to a few per cent), summed as two halves so that gemm256p_kernel's GELU epilogue can produce the
 // same numbers for its own outputs (same values, same order of additions => same bits; the batch-invariance tests cross
 // the two): half wm = rows [wm P/2, +P/2) of the image; inside a half, quad q (rows 4q..4q+3) goes to partial q & 3, each
-// partial adds its values in ascending row order IN THE 16-BIT TYPE, and the half is (p0 + p1) + (p2 + p3) in f32.
+// partial adds its values in ascending row order IN THE 16-BIT TYPE, the half is (p0 + p1) + (p2 + p3) in f32, and the
+// mean is (half0 + half1) / P rounded to the operand type.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, float* __restrict__ parts, int S, int P, int K) {
+__global__ __launch_bounds__(256) void colmean_kernel(const T* __restrict__ a, T* __restrict__ abar, int S, int P, int K) {
   const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
   if (n >= K) return;
   const T* base = a + ((size_t)b * S + 1) * K + n;
   const int half = P / 2;
+  float hs[2];
   for (int wm = 0; wm < 2; ++wm) {
     T p[4] = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};       // accumulated in the operand type, as the GELU epilogue does
     for (int q = 0; q < half / 4; ++q) {
@@ -1114,24 +1124,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, fl
 #pragma unroll
       for (int r = 0; r < 4; ++r) p[q & 3] = p[q & 3] + v[r];
     }
-    parts[((size_t)b * 2 + wm) * K + n] = ((float)p[0] + (float)p[1]) + ((float)p[2] + (float)p[3]);
+    hs[wm] = ((float)p[0] + (float)p[1]) + ((float)p[2] + (float)p[3]);
   }
-}
-
-// mean16_kernel: the mean row of every image as a 16-bit MFMA operand, abar[b][k] = inv * (parts[b][0][k] + ... ), parts
-// added in ascending order.
-template <typename T>
-__global__ __launch_bounds__(256) void mean16_kernel(const float* __restrict__ parts, int nparts, float inv, T* __restrict__ abar, int K) {
-  const int b = blockIdx.y, k4 = blockIdx.x * 256 + threadIdx.x;
-  if (k4 * 4 >= K) return;
-  const f32x4* p = reinterpret_cast<const f32x4*>(parts + (size_t)b * nparts * K) + k4;
-  f32x4 s = p[0];
-  for (int q = 1; q < nparts; ++q) s += p[(size_t)q * (K / 4)];
-  typedef T x4 __attribute__((ext_vector_type(4)));
-  x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (T)(s[j] * inv);
-  reinterpret_cast<x4*>(abar + (size_t)b * K)[k4] = o;
+  abar[(size_t)b * K + n] = (T)((hs[0] + hs[1]) * (1.f / (float)P));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1207,10 +1202,10 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   const int ncu = di.ncu;
   constexpr int G64_MAXM = 2047;       // rows up to which a GEMM is cut into 64x64 tiles (pure latency below that)
   constexpr int CAT_COMP = 8;          // HVLA_PROF_COMP
-  const bool comp = w.layer[0].dqkv != nullptr && ws.parts && ws.corr && ws.abar;
+  const bool comp = w.layer[0].dqkv != nullptr && ws.corr && ws.abar;
   // ---- one GEMM of the encoder: activations [B*S rows][K] -> [B*S rows][N], with the per-image bias rows that compensate
-  // the rounding of W (dW = the rounding residue x 4096; the mean row of the activation operand is in ws.abar, or comes
-  // from `nparts` partial column sums in ws.parts times `inv`)
+  // the rounding of W (dW = the rounding residue x 4096; the mean row of the activation operand is in ws.abar, written by
+  // the kernel that produced the operand)
   //  * images of 256 patches, batch >= 8, N % 256 == 0: ONE gemm64_kernel launch for the 2 B latency-bound rows (the B CLS
   //    rows, stride S, plain bias; the B mean rows against dW -> ws.corr), then gemm256p_kernel over image-aligned tiles
   //    (tile row b = rows b*S + 1 .. b*S + 256 = the patch rows of image b) with ws.corr as its bias rows;
@@ -1218,15 +1213,12 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   //    looked up per row.
   // Returns whether the image-aligned form ran (then a GELU epilogue writes the mean row of its output itself).
   auto gemm = [&](auto epic, const void* A, const void* Wt, const void* dW, int N, int K, const float* bias, const float* aux,
-                  void* out, int qcols, int cat, int nparts, float inv, void* colmean = nullptr) -> bool {
+                  void* out, int qcols, int cat, void* colmean = nullptr) -> bool {
     constexpr int EPI = decltype(epic)::value;
     GemmArgs a{A, Wt, M, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
     const bool fits32 = (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
     const bool aligned = P == HBM_ && N % HBN_ == 0 && M > G64_MAXM && K >= 128 && K % 64 == 0 && fits32;
     pf.begin(CAT_COMP, st);
-    if (comp && nparts > 0)
-      hipLaunchKernelGGL((mean16_kernel<T>), dim3((K / 4 + 255) / 256, B), dim3(256), 0, st, ws.parts, nparts, inv,
-                         reinterpret_cast<T*>(ws.abar), K);
     if (aligned) {
       GemmArgs c = a;                                  // the B CLS rows (+ the B mean rows -> ws.corr)
       c.M = B; c.row0 = 0; c.row_step = S;
@@ -1259,17 +1251,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     pf.end(cat, st);
     return false;
   };
-  const int nchunk = (S + 15) / 16;
   auto layernorm = [&](const float* sc, const float* bi) {           // norm1 / norm2 (+ the column sums of the output)
-    if (comp)
-      hipLaunchKernelGGL((layernorm_cs_kernel<Op>), dim3(nchunk, B), dim3(256), (size_t)4 * E * sizeof(float), st, ws.x,
-                         reinterpret_cast<T*>(ws.h), sc, bi, ws.parts, S, E);
-    else
-      hipLaunchKernelGGL((layernorm_kernel<Op, 0>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, ws.h, sc, bi, M, E, S);
+    hipLaunchKernelGGL((layernorm_img_kernel<Op>), dim3(B), dim3(LNW * 64), (size_t)LNW * E * sizeof(float), st, ws.x,
+                       reinterpret_cast<T*>(ws.h), sc, bi, comp ? reinterpret_cast<T*>(ws.abar) : nullptr, S, E);
   };
-  auto colsum_of = [&](const void* act, int K) {
+  auto colmean_of = [&](const void* act, int K) {      // mean row of a GEMM output whose epilogue did not write it (no image-aligned tiles)
     if (!comp) return;
-    hipLaunchKernelGGL((colsum_kernel<T>), dim3((K + 255) / 256, B), dim3(256), 0, st, reinterpret_cast<const T*>(act), ws.parts, S, P, K);
+    hipLaunchKernelGGL((colmean_kernel<T>), dim3((K + 255) / 256, B), dim3(256), 0, st, reinterpret_cast<const T*>(act),
+                       reinterpret_cast<T*>(ws.abar), S, P, K);
   };
   auto audit_of = [&](const void* buf, size_t n, int site) {      // site: 0 LayerNorm out, 1 q/k/v, 2 attention out, 3 GELU out
     if (!audit) return;
@@ -1310,22 +1299,22 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     layernorm(L.ln1_s, L.ln1_b);
     pf.end(1, st);
     audit_of(ws.h, (size_t)M * E, 0);
-    gemm(EQ{}, ws.h, L.wqkv, L.dqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, 2, nchunk, 1.f / (float)S);
+    gemm(EQ{}, ws.h, L.wqkv, L.dqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, 2);                       // the LayerNorm wrote the mean row itself
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
     pf.begin(3, st);
     hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
                        reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr);
     pf.end(3, st);
     audit_of(ws.h, (size_t)M * E, 2);
-    gemm(ER{}, ws.h, L.wo, L.dwo, E, E, L.bo, L.ls1, ws.x, 0, 4, 0, 0.f);           // the attention kernel wrote the mean row itself
+    gemm(ER{}, ws.h, L.wo, L.dwo, E, E, L.bo, L.ls1, ws.x, 0, 4);                     // the attention kernel wrote the mean row itself
     pf.begin(1, st);
     layernorm(L.ln2_s, L.ln2_b);
     pf.end(1, st);
     audit_of(ws.h, (size_t)M * E, 0);
-    const bool summed = gemm(EG{}, ws.h, L.w1, L.dw1, F, E, L.b1, nullptr, ws.g, 0, 5, nchunk, 1.f / (float)S, comp ? ws.abar : nullptr);
+    const bool summed = gemm(EG{}, ws.h, L.w1, L.dw1, F, E, L.b1, nullptr, ws.g, 0, 5, comp ? ws.abar : nullptr);
     audit_of(ws.g, (size_t)M * F, 3);
-    if (!summed) colsum_of(ws.g, F);                                                  // aligned tiles: the GELU epilogue wrote the mean row
-    gemm(ER{}, ws.g, L.w2, L.dw2, E, F, L.b2, L.ls2, ws.x, 0, 6, summed ? 0 : 2, 1.f / (float)P);
+    if (!summed) colmean_of(ws.g, F);                                                 // aligned tiles: the GELU epilogue wrote the mean row
+    gemm(ER{}, ws.g, L.w2, L.dw2, E, F, L.b2, L.ls2, ws.x, 0, 6);
   }
   pf.begin(1, st);
   if (keep_cls)

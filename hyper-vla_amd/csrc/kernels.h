@@ -57,7 +57,6 @@ struct EncWorkspace {
   void* h;         // [B*S, E] 16-bit LN output / attention output
   void* qkv;       // [B*S, 3E] 16-bit
   void* g;         // [B*S, F] 16-bit MLP hidden; also holds the im2col matrix [B*P, Kp]
-  float* parts;    // [B, 2, max(E, F)] column sums of the current GEMM's activation operand over each image's patch rows
   float* corr;     // [B, max(3E, F)] per-image bias row of the current GEMM (bias + mean row . dW)
   void* abar;      // [B, max(E, F)] 16-bit mean row of the current GEMM's activation operand
 };

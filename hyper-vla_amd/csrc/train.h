@@ -69,8 +69,12 @@ struct TrainHyper {
   int step, forward_only;
   float base_lr, base_weight_decay;      // optimizer group of the shared (DINOv2) leaves, train_utils.py:411-419
 };
+// bucket_done (nullable, [3]): events recorded on `st` when a contiguous range of `grads` is final -- [0] the shared DINOv2
+// leaves [total, total + enc_total) after the image encoder's backward (trained encoder only), [1] the output heads
+// [wcat, total) after the weight-generation backward, [2] the context encoder [0, wcat) at the end -- so that the caller's
+// all-reduce of a bucket runs under the rest of the backward pass.
 hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& tb, const TrainInputs& in, int B,
-                      const TrainHyper& hp, hipStream_t st);
+                      const TrainHyper& hp, hipStream_t st, hipEvent_t* bucket_done = nullptr);
 hipError_t train_apply(const TrainLayout& L, const TrainBuffers& tb, const TrainHyper& hp, bool train_encoder, hipStream_t st);
 hipError_t train_accumulate(const TrainLayout& L, const TrainBuffers& tb, float* acc, float inv_k, const TrainHyper& hp,
                             bool train_encoder, hipStream_t st);

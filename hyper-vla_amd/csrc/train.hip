@@ -1052,7 +1052,7 @@ size_t train_workspace_floats(const Geom& g, int B, bool train_encoder) {
 }
 
 hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& tb, const TrainInputs& in, int B,
-                      const TrainHyper& hp, hipStream_t st) {
+                      const TrainHyper& hp, hipStream_t st, hipEvent_t* bucket_done) {
   const int S = g.S(), P = g.P(), D = g.D, H = g.H, F = g.M, E = g.E;
   const int Sc = g.T + 2, C = g.C, Hc = g.ctx_heads, Fc = g.ctx_mlp, T = g.T;
   const int Se = P + 1, He = g.enc_heads, Fe = g.enc_mlp, Kp = g.patch * g.patch * 3;
@@ -1142,6 +1142,7 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
     (void)hipMemcpyAsync(Ge + L.e_cls, Ge + L.e_pos, (size_t)E * 4, hipMemcpyDeviceToDevice, st);                          // dcls = dpos[0]
     KL(colsum_kernel, dim3((E + 63) / 64, 1, (P + 63) / 64), dim3(64), Ge + L.e_pos + E, Ge + L.e_pb, 0, P, P, E, 1);     // dbias = sum_{t>=1} dpos[t]
     bgemm(st, true, false, BG{pl.patches, edx + E, Ge + L.e_pk, nullptr, Kp, E, P, Kp, E, E, (long)P * Kp, 0, (long)Se * E, 0, 0, 0, 0, 1, 1.f, 2}, B);
+    if (bucket_done) (void)hipEventRecord(bucket_done[0], st);           // the shared DINOv2 leaves are final
   }
   // =============================== weight generation backward ===============================
   bgemm(st, true, false, BG{ctx, tb.dtheta, Gm + L.wcat, nullptr, C, (int)G, B, C, (int)G, (int)G, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1}, 1);   // dW_cat = ctx^T dtheta
@@ -1149,6 +1150,7 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   (void)hipMemsetAsync(dctx, 0, (size_t)B * C * 4, st);
   // dctx = dtheta W_cat^T: [B, G] x [G, C], a K = 201 500 product onto a B x C output -> split-K over the whole chip
   bgemm(st, false, true, BG{tb.dtheta, Pm + L.wcat, dctx, nullptr, B, C, (int)G, (int)G, (int)G, C, 0, 0, 0, 0, 0, 0, 0, 1, 1.f, 1, 1, 1}, 1);
+  if (bucket_done) (void)hipEventRecord(bucket_done[1], st);             // W_cat, b_cat are final
   // =============================== context encoder backward ===============================
   (void)hipMemsetAsync(cdx, 0, (size_t)B * Sc * C * 4, st);
   KL(ctx_final_bwd_kernel, dim3((B + 3) / 4), dim3(256), cx_fin + (long)(Sc - 1) * C, (long)Sc * C, dctx, cmean, crstd, Pm + L.norm_s, cdx + (long)(Sc - 1) * C, Gm + L.norm_s, Gm + L.norm_b, B, C, g.scale_context ? 1.f / sqrtf((float)C) : 1.f);
@@ -1158,6 +1160,7 @@ hipError_t train_step(const Geom& g, const TrainLayout& L, const TrainBuffers& t
   KL(ctx_rows_bwd_kernel, g1((long)B * Sc * C), dim3(256), cdx, Gm + L.pos_tok, Gm + L.pos_img, Gm + L.pos_layer, Gm + L.b_tok, Gm + L.b_img, B, T, C);
   bgemm(st, true, false, BG{in.tok, cdx, Gm + L.w_tok, nullptr, g.lang_dim, C, T, g.lang_dim, C, C, (long)T * g.lang_dim, 0, (long)Sc * C, 0, 0, 0, 0, 1, 1.f, 2}, B);
   bgemm(st, true, false, BG{in.cls, cdx + (long)T * C, Gm + L.w_img, nullptr, E, C, 1, E, C, C, (long)E, 0, (long)Sc * C, 0, 0, 0, 0, 1, 1.f, 2}, B);
+  if (bucket_done) (void)hipEventRecord(bucket_done[2], st);             // the context encoder's leaves: everything is final
   return hipGetLastError();
 }
 

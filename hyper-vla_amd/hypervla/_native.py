@@ -19,7 +19,8 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
-           "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit", "hvla_train_accumulate"]
+           "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit", "hvla_train_accumulate", "hvla_train_bucket_ranges",
+           "hvla_train_wait_bucket"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy",
               "small_row_gemms"]      # mean rows + the 2 B latency-bound rows per GEMM: CLS rows and weight-rounding compensation rows
 
@@ -116,6 +117,10 @@ def load_library():
     lib.hvla_train_apply.argtypes = [vp, C.POINTER(hvla_train_buffers), C.POINTER(hvla_train_hyper), vp]
     lib.hvla_train_accumulate.argtypes = [vp, C.POINTER(hvla_train_buffers), vp, C.c_float, C.POINTER(hvla_train_hyper), vp]
     lib.hvla_train_accumulate.restype = C.c_int
+    lib.hvla_train_bucket_ranges.argtypes = [vp, i32, C.POINTER(C.c_int64)]
+    lib.hvla_train_bucket_ranges.restype = C.c_int
+    lib.hvla_train_wait_bucket.argtypes = [vp, i32, vp]
+    lib.hvla_train_wait_bucket.restype = C.c_int
     lib.hvla_train_apply.restype = C.c_int
     lib.hvla_profile.argtypes = [vp, i32]
     lib.hvla_profile.restype = C.c_int
@@ -262,6 +267,14 @@ class Context:
 
     def train_apply(self, buf, hyper, stream=0):
         self._check(self.lib.hvla_train_apply(self.h, C.byref(buf), C.byref(hyper), C.c_void_p(stream)), "hvla_train_apply")
+
+    def train_bucket_ranges(self, train_encoder):
+        out = (C.c_int64 * 6)()
+        self._check(self.lib.hvla_train_bucket_ranges(self.h, int(train_encoder), out), "hvla_train_bucket_ranges")
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(3)]
+
+    def train_wait_bucket(self, bucket, stream):
+        self._check(self.lib.hvla_train_wait_bucket(self.h, int(bucket), C.c_void_p(stream)), "hvla_train_wait_bucket")
 
     def train_accumulate(self, buf, acc_ptr, inv_k, hyper, stream=0):
         self._check(self.lib.hvla_train_accumulate(self.h, C.byref(buf), C.c_void_p(acc_ptr), C.c_float(inv_k), C.byref(hyper),

@@ -54,6 +54,24 @@ def train_param_layout(g: Geometry, train_encoder: bool = False) -> Tuple[List[T
     return out, off
 
 
+def gradient_buckets(g: Geometry, train_encoder: bool = False) -> List[Tuple[str, int, int]]:
+    """[(name, offset, length)] of the flat gradient in the order hvla_train_step finishes them (include/hvla.h,
+    hvla_train_bucket_ranges): the shared DINOv2 leaves after the image encoder's backward, the output heads (W_cat,
+    b_cat) after the weight-generation backward, the context encoder at the end of the step.  Contiguous, disjoint, and
+    together the whole vector -- what `pmean(grads)` (scripts/train.py:460) is cut into so that each all-reduce runs
+    under the rest of the backward pass."""
+    layout, total = train_param_layout(g, train_encoder)
+    at = {name: off for name, off, _ in layout}
+    wcat = at["W_cat"]
+    n_hyper = at["b_cat"] + generated_leaves(g)[-1].offset + generated_leaves(g)[-1].size
+    out = []
+    if train_encoder:
+        out.append(("image_encoder", n_hyper, total - n_hyper))
+    out.append(("output_heads", wcat, n_hyper - wcat))
+    out.append(("context_encoder", 0, wcat))
+    return out
+
+
 def pack_params(g: Geometry, params: Dict[str, np.ndarray], train_encoder: bool = False) -> np.ndarray:
     layout, total = train_param_layout(g, train_encoder)
     flat = np.zeros(total, np.float32)
@@ -181,6 +199,13 @@ class FineTuner:
                        base_weight_decay=base_weight_decay)
         self.peak_lr, self.base_peak_lr, self.step_count = peak_lr, base_lr, 0
         self.ema_start_step = int(ema_start_step)
+        self._bucket_setup()
+
+    def _bucket_setup(self):
+        self.buckets = gradient_buckets(self.g, self.train_encoder)
+        ranges = self.model._ctx.train_bucket_ranges(self.train_encoder)
+        self._bucket_id = [ranges.index((off, n)) for _, off, n in self.buckets]   # the library's numbering (0 encoder, 1 heads, 2 context)
+        self._comm = None
 
     def _buffers(self, grads):
         return _native.hvla_train_buffers(*[t.data_ptr() if t is not None else None for t in (
@@ -226,12 +251,30 @@ class FineTuner:
         m._ctx.train_step(self.buf, ptrs, self.B, self._hyper(0.0, forward_only), m._stream())
         return self.loss
 
-    def all_reduce_gradient(self):
-        """`pmean(grads)` of scripts/train.py:460 (RCCL over xGMI on the GPU box; gloo in the CPU tests)."""
+    def all_reduce_gradient(self, single_rank_too: bool = False):
+        """`pmean(grads)` of scripts/train.py:460, bucketed: RCCL over xGMI, one all-reduce per gradient bucket, each
+        enqueued on a communication stream that waits (on the device, hvla_train_wait_bucket) only for the event
+        hvla_train_step recorded when that bucket became final -- the 343 MB DINOv2 bucket is on the links while the
+        weight-generation and context-encoder backward still run.  Nothing here blocks the host; the compute stream
+        waits for the reductions before the optimizer reads `grads`.  (`single_rank_too`: run the same path in a
+        one-rank process group -- the tests' way of exercising the events and streams on a one-GPU box.)"""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads)
-            self.grads /= dist.get_world_size()
+        if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_too)):
+            return
+        torch, m = self.torch, self.model
+        world = dist.get_world_size()
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=m.device)
+        cur = torch.cuda.current_stream(m.device)
+        works = []
+        with torch.cuda.stream(self._comm):
+            for i, (_, off, n) in enumerate(self.buckets):
+                m._ctx.train_wait_bucket(self._bucket_id[i], self._comm.cuda_stream)
+                works.append(dist.all_reduce(self.grads[off:off + n], async_op=True))
+            for w in works:
+                w.wait()                                  # the communication stream waits for the collective
+            self.grads /= world                           # ... and scales behind it
+        cur.wait_stream(self._comm)
 
     def apply(self, lr=None, base_lr=None):
         """Gradient all-reduce, then the optimizer: chain(clip_by_global_norm, [MultiSteps](adamw)) and the EMA.  With

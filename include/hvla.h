@@ -181,6 +181,16 @@ int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* t
                     const uint8_t* images, const float* target, const uint8_t* timestep_mask,
                     const uint8_t* action_mask, int32_t B, const hvla_train_hyper* hyper, void* stream);
 int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_train_hyper* hyper, void* stream);
+/* Replaces: the point where scripts/train.py:460 `jax.lax.pmean(grads, "batch")` lets XLA overlap the gradient
+ * all-reduce with the backward pass.  hvla_train_step finishes `grads` in three contiguous buckets, in this order:
+ *   0  the shared DINOv2 leaves  [n_hyper, n_hyper + n_encoder)   (trained encoder only; after the image encoder's backward)
+ *   1  the output heads          [offset of W_cat, n_hyper)       (after the weight-generation backward)
+ *   2  the context encoder       [0, offset of W_cat)             (end of the step)
+ * hvla_train_bucket_ranges writes (offset, length) of buckets 0, 1, 2 into out[6] (length 0 = not produced);
+ * hvla_train_wait_bucket makes `stream` (the caller's communication stream) wait until bucket `bucket` of the LAST
+ * hvla_train_step is final, without blocking the host: the caller then enqueues its all-reduce of that range there.     */
+int hvla_train_bucket_ranges(hvla_ctx* ctx, int32_t train_encoder, int64_t out[6]);
+int hvla_train_wait_bucket(hvla_ctx* ctx, int32_t bucket, void* stream);
 /* Replaces: one micro-step of optax.MultiSteps under the reference's chain(clip_by_global_norm, MultiSteps(adamw))
  * (octo/utils/train_utils.py:420-426, grad_accumulation_steps > 1): acc += clip_by_global_norm(buf->grads) * inv_k.
  * After k micro-steps the caller runs hvla_train_apply with `grads` pointing at acc and hyper.clip = +inf.        */

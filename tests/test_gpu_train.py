@@ -454,3 +454,49 @@ def test_data_parallel_step_equals_the_big_batch_step(tmp_path):
     big = np.abs(gsingle) > 1e-4 * gmax
     moved = np.abs(single - before)[big].max()
     assert moved > 0 and np.abs(dp - single)[big].max() <= 1e-2 * moved, (np.abs(dp - single)[big].max(), moved)
+
+
+def test_bucketed_all_reduce_path_on_one_rank(tmp_path):
+    """FineTuner.all_reduce_gradient cuts `pmean(grads)` (scripts/train.py:460) into the three buckets hvla_train_step
+    finishes in turn and enqueues each all-reduce on a communication stream behind the bucket's event.  One GPU here, so a
+    one-rank RCCL group: the reduction is the identity, which is the check -- every bucket goes through event, stream and
+    collective and comes back unchanged, and the optimizer step behind it equals the step without the group."""
+    import torch
+    import torch.distributed as dist
+    from hypervla import synthetic as syn
+    from hypervla.config import MID
+    from hypervla.model import HyperVLA
+    from hypervla.train import FineTuner
+    g, B = MID, 4
+    model = HyperVLA.from_synthetic(g, max_batch=B)
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    batch = syn.synthetic_action_batch(B, g)
+    ref = FineTuner(model, B, train_encoder=True)
+    ref.forward_backward(ins, st, im, batch)
+    g_ref = ref.grads.clone()
+    ref.apply(lr=1e-3, base_lr=1e-4)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", world_size=1, rank=0)
+    try:
+        ft = FineTuner(model, B, train_encoder=True)
+        assert [b[0] for b in ft.buckets] == ["image_encoder", "output_heads", "context_encoder"] and ft._bucket_id == [0, 1, 2]
+        ft.forward_backward(ins, st, im, batch)
+        ft.all_reduce_gradient(single_rank_too=True)                 # enqueued behind the step, nothing synchronised in between
+        torch.cuda.synchronize()
+        scale = float(g_ref.abs().max())
+        assert float((ft.grads - g_ref).abs().max()) <= 1e-5 * scale   # (two runs of the step differ in the last bits: split-K sums)
+        ft.forward_backward(ins, st, im, batch)
+        torch.cuda.synchronize()
+        g0 = ft.grads.clone()
+        ft.all_reduce_gradient(single_rank_too=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ft.grads, g0)                             # one rank: the reduction is the identity, bit for bit
+        with pytest.raises(RuntimeError, match="bucket"):           # a frozen-encoder step produces no encoder bucket
+            fz = FineTuner(model, B)
+            fz.forward_backward(ins, st, model.encode_images(im), batch)
+            model._ctx.train_wait_bucket(0, 0)
+        ft.forward_backward(ins, st, im, batch)                       # events are re-recorded by every step
+        ft.apply(lr=1e-3, base_lr=1e-4)
+        # the same update; Adam's first step is lr * sign(g), so the few gradients whose last bits straddle 0 may differ
+        assert float(((ft.params - ref.params).abs() > 1e-5).float().mean()) < 1e-3
+    finally:
+        dist.destroy_process_group()

@@ -162,3 +162,23 @@ def test_weight_decay_masks_follow_the_reference_strategies():
             assert not a.any() and bool(b.all()) == ("kernel" in name)
     with pytest.raises(ValueError):
         weight_decay_mask(g, "v3")
+
+
+def test_gradient_buckets_tile_the_flat_vector():
+    """The three all-reduce buckets (image encoder | output heads | context encoder, in the order the backward pass
+    finishes them) are contiguous, disjoint and cover the flat gradient; the frozen-encoder layout has two."""
+    from hypervla.config import FULL, MID
+    from hypervla.train import gradient_buckets, train_param_layout
+    for g in (MID, FULL):
+        for enc in (False, True):
+            layout, total = train_param_layout(g, enc)
+            b = gradient_buckets(g, enc)
+            assert [n for n, _, _ in b] == (["image_encoder"] if enc else []) + ["output_heads", "context_encoder"]
+            spans = sorted((off, off + n) for _, off, n in b)
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == c[0] for a, c in zip(spans, spans[1:]))
+            at = {name: off for name, off, _ in layout}
+            heads = dict((n, (o, l)) for n, o, l in b)["output_heads"]
+            assert heads[0] == at["W_cat"] and heads[0] + heads[1] == (total if not enc else dict((n, (o, l)) for n, o, l in b)["image_encoder"][0])
+    enc_bucket = gradient_buckets(FULL, True)[0]
+    assert enc_bucket[2] > 85_000_000 and enc_bucket[2] * 4 > 340e6            # the 343 MB bucket that overlaps
