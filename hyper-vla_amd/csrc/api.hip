@@ -813,7 +813,8 @@ int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches) {
   return HVLA_OK;
 }
 
-// diagnostics (not part of include/hvla.h): one encoder GEMM shape on the ctx's workspace
+#ifdef HVLA_BENCH_HOOKS
+// diagnostics (libhvla_bench.so only; not part of include/hvla.h): one encoder GEMM shape on the ctx's workspace
 int hvla_debug_gemm(hvla_ctx* ctx, int M, int N, int K, int epi, int variant, int iters, float* ms) {
   if (!ctx || !ctx->loaded) return HVLA_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -846,6 +847,14 @@ int hvla_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int
   (void)hipEventDestroy(e1);
   return hipGetLastError() == hipSuccess ? HVLA_OK : HVLA_E_HIP;
 }
+
+// the fine-tune GEMM on the exact-f32 matrix instruction (bitwise fmaf chains) instead of split-bf16: a debugging aid for
+// gradient comparisons, so it is a call in the bench library and not an environment switch of the product
+int hvla_debug_train_gemm_exact(int on) {
+  set_train_gemm_exact(on != 0);
+  return HVLA_OK;
+}
+#endif  // HVLA_BENCH_HOOKS
 
 int hvla_selftest(hvla_ctx* ctx, void* stream) {
   if (!ctx) return HVLA_E_STATE;

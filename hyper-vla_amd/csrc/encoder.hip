@@ -1325,7 +1325,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   return hipGetLastError();
 }
 
-// diagnostics (tools/gemm_bench.py): time `iters` launches of one encoder GEMM shape on workspace buffers (contents
+#ifdef HVLA_BENCH_HOOKS
+// diagnostics, libhvla_bench.so only (tools/gemm_bench.py): time `iters` launches of one encoder GEMM shape on workspace buffers (contents
 // irrelevant).  variant 0: gemm_kernel (128x128), 1: gemm64_kernel, 2: gemm256p_kernel one workgroup per tile,
 // 3: gemm256p_kernel persistent.  M is rounded down to whole 256-row tiles for variants 2 and 3.
 hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
@@ -1373,6 +1374,7 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
   (void)hipEventDestroy(e1);
   return hipGetLastError();
 }
+#endif  // HVLA_BENCH_HOOKS
 
 hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const EncWorkspace& ws,
                           const uint8_t* images, float* tokens, int B, hipStream_t st, Profiler* prof, bool keep_cls,

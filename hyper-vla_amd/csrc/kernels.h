@@ -88,8 +88,10 @@ hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const E
                           bool keep_cls = false,    // keep_cls: tokens = f32 [B, S, E] last_hidden_state
                           uint32_t* audit = nullptr);   // [4 sites][2]: max |16-bit operand| (float bits), non-finite count
 
+#ifdef HVLA_BENCH_HOOKS
 hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st);
+#endif
 
 // ---------------------------------------------------------------- observation preprocessing (resize.hip)
 void build_resize_spans(int in_size, int out_size, std::vector<int>& start, std::vector<int>& count, std::vector<float>& w,

@@ -35,6 +35,9 @@ struct TrainLayout {
   struct EL { long kb, kk, qb, qk, vb, vk, ob, ok, ls1, ls2, f1b, f1k, f2b, f2k, n1b, n1s, n2b, n2s; } enc[24];
 };
 TrainLayout make_train_layout(const Geom& g);
+#ifdef HVLA_BENCH_HOOKS
+void set_train_gemm_exact(bool on);
+#endif
 size_t train_workspace_floats(const Geom& g, int B, bool train_encoder);
 
 struct TrainBuffers {        // all device memory, owned by the caller

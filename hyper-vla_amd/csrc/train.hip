@@ -341,11 +341,15 @@ static void launch_bgemm3(hipStream_t st, bool ta, bool tb, const BG& g, dim3 gr
   else hipLaunchKernelGGL((bgemm3_kernel<true, true, BM, BN, VEC>), grid, dim3(256), 0, st, g);
 }
 
-// HVLA_TRAIN_GEMM=f32 selects the exact-f32 matrix instruction (bitwise fmaf chains) instead of the split-bf16 path
-static bool train_gemm_exact() {
-  static const int v = [] { const char* e = getenv("HVLA_TRAIN_GEMM"); return e && !strcmp(e, "f32") ? 1 : 0; }();
-  return v != 0;
-}
+// the exact-f32 matrix instruction (bitwise fmaf chains) instead of the split-bf16 path: libhvla_bench.so only
+// (hvla_debug_train_gemm_exact); the product library has no switch that changes its arithmetic
+#ifdef HVLA_BENCH_HOOKS
+static bool g_train_gemm_exact = false;
+void set_train_gemm_exact(bool on) { g_train_gemm_exact = on; }
+static bool train_gemm_exact() { return g_train_gemm_exact; }
+#else
+static constexpr bool train_gemm_exact() { return false; }
+#endif
 
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
   const bool exact = train_gemm_exact();
@@ -353,7 +357,7 @@ void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
   // deep-K products onto few output tiles (shared-weight gradients: K = all rows of the batch) would leave most CUs
   // idle: cut K so that the grid has >= ~256 workgroups (one per CU; more only adds atomic traffic); legal whenever the result is accumulated (C zeroed before)
   const long tiles = (long)((g.N + T - 1) / T) * ((g.M + T - 1) / T) * nb0 * g.nb1;
-  static const long want = [] { const char* e = getenv("HVLA_KSPLIT_TILES"); return e ? atol(e) : 256L; }();
+  constexpr long want = 256;
   if (g.allow_split && g.accumulate != 0 && g.ksplit == 1 && tiles < want && g.K >= 256) {
     long ks = (want + tiles - 1) / tiles, kmax = g.K / 128;
     g.ksplit = (int)(ks < kmax ? ks : kmax);

@@ -8,7 +8,9 @@ from typing import Dict, Optional
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libhvla.so")
+_LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
+# HVLA_LIBRARY_FLAVOUR=bench: tools/ load libhvla_bench.so (the same sources with the hvla_debug_* timing hooks compiled in)
+_LIB_PATH = os.path.join(_LIB_DIR, "libhvla_bench.so" if os.environ.get("HVLA_LIBRARY_FLAVOUR") == "bench" else "libhvla.so")
 
 HVLA_ENC_F16, HVLA_ENC_BF16 = 0, 1
 _ERRORS = {-1: "HVLA_E_SHAPE", -2: "HVLA_E_DTYPE", -3: "HVLA_E_DEVICE", -4: "HVLA_E_ARENA_FULL",

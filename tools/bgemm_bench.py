@@ -1,5 +1,6 @@
 """Diagnostic (GPU box): time shapes of the fine-tune path's batched split-bf16 GEMM in isolation (hvla_debug_bgemm)."""
 import ctypes as C, os, sys
+os.environ["HVLA_LIBRARY_FLAVOUR"] = "bench"        # libhvla_bench.so: the product library has no hvla_debug_* entry points
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hyper-vla_amd"))
 import torch

@@ -4,6 +4,7 @@
                                           2 gemm256p_kernel one workgroup per tile, 1 gemm64_kernel, 0 gemm_kernel (128x128)
 M = B x 256 rows (whole image-aligned tiles, as in the encoder)."""
 import ctypes as C, os, sys
+os.environ["HVLA_LIBRARY_FLAVOUR"] = "bench"        # libhvla_bench.so: the product library has no hvla_debug_* entry points
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hyper-vla_amd")); sys.path.insert(0, ROOT)
 import torch
