@@ -441,8 +441,11 @@ static int check_step(hvla_ctx* ctx, int32_t B) {
 static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0, int nb, bool keep_cls, hipStream_t st) {
   const Geom& g = ctx->g;
   const size_t S = g.S(), E = g.E, F = g.enc_mlp, rows = (size_t)b0 * S;
+  // ws_g holds an episode's MLP hidden rows [S][F] and, before that, its im2col rows [P][Kp]: the slices of two concurrent
+  // halves must be disjoint for the larger of the two
+  const size_t gper = S * F > (size_t)g.P() * ctx->Kp ? S * F : (size_t)g.P() * ctx->Kp;
   EncWorkspace ws{ctx->ws_x.as<float>() + rows * E, static_cast<char*>(ctx->ws_h.p) + rows * E * 2,
-                  static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + rows * F * 2,
+                  static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + (size_t)b0 * gper * 2,
                   ctx->ws_corr.as<float>() + (size_t)b0 * (F > 3 * E ? F : 3 * E),
                   static_cast<char*>(ctx->ws_abar.p) + (size_t)b0 * (F > E ? F : E) * 2};
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
@@ -846,6 +849,25 @@ int hvla_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return hipGetLastError() == hipSuccess ? HVLA_OK : HVLA_E_HIP;
+}
+
+// phase time stamps of the policy kernel (episode 0, wave 0; shader clock): 27 values at the README geometry, policy.hip HVLA_STAMP
+int hvla_debug_policy_stamps(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float* actions, float* logits, int32_t B,
+                             unsigned long long* out, int32_t n) {
+  if (!ctx || !w || !out) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const Geom& g = ctx->g;
+  const PolicyLayout& pl = ctx->lay.pl;
+  DevBuf st;
+  HIPCHK(ctx, st.alloc((size_t)n * 8));
+  HIPCHK(ctx, hipMemset(st.p, 0, (size_t)n * 8));
+  PolicyParams p{pl, w->wh.as<__bf16>(), w->wl.as<__bf16>(), w->vf.as<float>(), tokens, actions, logits,
+                 B, g.E, g.P(), g.L, g.M, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
+  p.stamps = st.as<unsigned long long>();
+  for (int i = 0; i < 3; ++i) HIPCHK(ctx, launch_policy(p, nullptr));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, hipMemcpy(out, st.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return HVLA_OK;
 }
 
 // the fine-tune GEMM on the exact-f32 matrix instruction (bitwise fmaf chains) instead of split-bf16: a debugging aid for

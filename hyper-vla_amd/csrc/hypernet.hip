@@ -319,12 +319,15 @@ hipError_t launch_ctx_encoder(const CtxParams& p, int B, hipStream_t st) {
   size_t big_elems = (size_t)S * bigld;
   if (big_elems < (size_t)p.E) big_elems = p.E;
   const size_t smem = ((size_t)2 * S * ldx + big_elems) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ctx_encoder_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static bool attr_done[64] = {};                              // per device: the attribute belongs to the device's code object
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ctx_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[dev] = true;
   }
   if (smem > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ctx_encoder_kernel, dim3(B), dim3(CTX_THREADS), smem, st, p);

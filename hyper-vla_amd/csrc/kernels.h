@@ -111,6 +111,9 @@ struct PolicyParams {
   float* logits;             // [B, horizon] or null
   int B, E, P, L, M, horizon, action_dim;
   float tanh_scale, max_action;
+#ifdef HVLA_BENCH_HOOKS
+  unsigned long long* stamps = nullptr;   // libhvla_bench.so: shader-clock time stamps of episode 0 / wave 0 at the phase boundaries
+#endif
 };
 hipError_t launch_policy(const PolicyParams& p, hipStream_t st);
 

@@ -33,7 +33,8 @@ static uint16_t f2bf(float f) {
 template <int TIE>
 static int run_variant(const PolicyParams& p, int launches, bool loaded, const float4* sa, float4* sb, size_t sn) {
   constexpr int NW = 8, SP = (NW + 1) * 32, VLD = SP + 8;
-  const size_t smem = (size_t)PRING * 8192 + ((size_t)2 * 2 * SP * 16 + (size_t)2 * 32 * VLD) * sizeof(__bf16) + (size_t)(NW + 1) * 4096;
+  const size_t smem = (size_t)PRING * 8192 + ((size_t)2 * 2 * SP * 16 + (size_t)2 * 32 * VLD) * sizeof(__bf16) + (size_t)(NW + 1) * 4096 +
+                      (size_t)(p.pl.Gv - p.pl.v_layer0) * sizeof(float);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_kernel<NW, TIE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const size_t nact = (size_t)p.B * p.horizon * p.action_dim;
   std::vector<float> first(nact), cur(nact);
