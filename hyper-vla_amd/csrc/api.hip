@@ -851,6 +851,23 @@ int hvla_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int
   return hipGetLastError() == hipSuccess ? HVLA_OK : HVLA_E_HIP;
 }
 
+// phase time stamps of attention_kernel for workgroups `wgs[i]` (8 stamps each), on the ctx's workspace (contents irrelevant)
+int hvla_debug_attention_stamps(hvla_ctx* ctx, int32_t B, const int32_t* wgs, int32_t nwg, unsigned long long* out) {
+  if (!ctx || !out || !wgs) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const Geom& g = ctx->g;
+  DevBuf st;
+  HIPCHK(ctx, st.alloc((size_t)8 * 8));
+  for (int i = 0; i < nwg; ++i) {
+    HIPCHK(ctx, hipMemset(st.p, 0, 64));
+    for (int rep = 0; rep < 2; ++rep)
+      HIPCHK(ctx, debug_attention_stamps(ctx->ws_qkv.p, ctx->ws_h.p, ctx->ws_abar.p, B, g.S(), g.E, g.enc_heads, wgs[i], st.as<unsigned long long>(), nullptr));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out + (size_t)i * 8, st.p, 64, hipMemcpyDeviceToHost));
+  }
+  return HVLA_OK;
+}
+
 // phase time stamps of the policy kernel (episode 0, wave 0; shader clock): 27 values at the README geometry, policy.hip HVLA_STAMP
 int hvla_debug_policy_stamps(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float* actions, float* logits, int32_t B,
                              unsigned long long* out, int32_t n) {

@@ -875,7 +875,19 @@ __device__ __forceinline__ float lane_bcast(float v, int l) {
 // weight-rounding compensation (the corr rows of gemm64_kernel): the workgroup owns every row of its 64 columns.
 template <typename Op>
 __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, typename Op::elem* __restrict__ o,
-                                 int S, int E, int H, typename Op::elem* __restrict__ omean) {
+                                 int S, int E, int H, typename Op::elem* __restrict__ omean
+#ifdef HVLA_BENCH_HOOKS
+                                 , unsigned long long* stamps = nullptr      // libhvla_bench.so: shader-clock stamps of workgroup `stamp_wg`, wave 0
+                                 , int stamp_wg = 0
+#endif
+                                 ) {
+#ifdef HVLA_BENCH_HOOKS
+  int nstamp = 0;
+#define HVLA_ASTAMP() do { if (stamps && (int)blockIdx.x == stamp_wg && threadIdx.x == 0) stamps[nstamp] = __builtin_readcyclecounter(); ++nstamp; } while (0)
+#else
+#define HVLA_ASTAMP() do { } while (0)
+#endif
+  HVLA_ASTAMP();                                           // 0 start
   // S = 32 * NW + 1 tokens.  NW waves of 64 lanes: wave w owns queries [32 w, 32 w + 32) on the matrix cores;
   // the one remaining query (the last token) is done co-operatively on the VALU, wave w taking key tile w,
   // and combined through LDS.  8 waves per workgroup at S = 257 (2 per SIMD) so that two workgroups share a
@@ -931,6 +943,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     if (i < SP * 8) *reinterpret_cast<X8*>(Ks + key * AVLD + ((ch ^ (key & 7)) * 8)) = kreg[it];
   }
   __syncthreads();
+  HVLA_ASTAMP();                                           // 1 K staged
   auto stage_v = [&] {
 #pragma unroll
     for (int it = 0; it < STG; ++it) {
@@ -983,7 +996,9 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   for (int kt = 0; kt < KT - 1; ++kt) rowmax(qk(kt, zero16()));
   rowmax(qk(KT - 1, mask16()));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  HVLA_ASTAMP();                                           // 2 pass 1 done
   stage_v();
+  HVLA_ASTAMP();                                           // 3 V staged
   typedef float f32x2v __attribute__((ext_vector_type(2)));
   f32x2v lsum2 = {0.f, 0.f};        // this half's partial denominator (two interleaved partial sums)
   f32x16 O[2];
@@ -1012,6 +1027,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   pv(KT - 1, qk(KT - 1, mask16()));
   const float lsum = lsum2[0] + lsum2[1];
   const float inv = 1.f / (lsum + __shfl_xor(lsum, 32, 64));
+  HVLA_ASTAMP();                                           // 4 pass 2 done
   {
     T* op = o + ((size_t)b * S + q) * E + head * 64;
 #pragma unroll
@@ -1032,6 +1048,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         *reinterpret_cast<typename Op::x4*>(op + mt * 32 + g4 * 8 + half * 4) = v4;
       }
   }
+  HVLA_ASTAMP();                                           // 5 normalised, column sums, stores issued
   // ---- the last query, VALU: wave w scores key tile w (lane = key, the two halves split d), the last wave also the
   // final key S-1; partial softmax + partial P.V (lane = d); combine across waves through LDS.
   {
@@ -1078,6 +1095,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     }
   }
   __syncthreads();
+  HVLA_ASTAMP();                                           // 6 last-query partials done
   if (wave == 0) {
     float M = -1e30f;
     for (int t = 0; t < KT; ++t) M = fmaxf(M, part[t * 66]);
@@ -1095,6 +1113,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       omean[(size_t)b * E + head * 64 + lane] = (T)((t + last) / (float)S);
     }
   }
+  HVLA_ASTAMP();                                           // 7 end
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1372,6 +1391,19 @@ hipError_t debug_gemm(const void* A, const void* W, const float* bias, const flo
   *ms /= iters;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  return hipGetLastError();
+}
+// phase stamps of attention_kernel (tools/attention_timeline.py): one launch over B * H workgroups on workspace-shaped buffers
+hipError_t debug_attention_stamps(const void* qkv, void* o, void* omean, int B, int S, int E, int H, int wg, unsigned long long* stamps,
+                                  hipStream_t st) {
+  using Op = OpF16;
+  using T = Op::elem;
+  const int KT = (S + 31) / 32;
+  const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * 66 * sizeof(float) + 64 * sizeof(T) +
+                           (size_t)(KT - 1) * 64 * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<Op>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st, reinterpret_cast<const T*>(qkv),
+                     reinterpret_cast<T*>(o), S, E, H, reinterpret_cast<T*>(omean), stamps, wg);
   return hipGetLastError();
 }
 #endif  // HVLA_BENCH_HOOKS

@@ -91,6 +91,8 @@ hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const E
 #ifdef HVLA_BENCH_HOOKS
 hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st);
+hipError_t debug_attention_stamps(const void* qkv, void* o, void* omean, int B, int S, int E, int H, int wg, unsigned long long* stamps,
+                                  hipStream_t st);
 #endif
 
 // ---------------------------------------------------------------- observation preprocessing (resize.hip)
