@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): encoder token error vs the float64 oracle, by depth and operand type."""
 import dataclasses, sys, os
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "hyper-vla_amd")); sys.path.insert(0, ROOT)
 from hypervla import synthetic as syn
 from hypervla.config import MID, encoder_leaves, generated_leaves

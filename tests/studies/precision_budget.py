@@ -1,6 +1,6 @@
 """CPU study: which 16-bit rounding sites of the GPU image encoder cost how much action error.
 
-    python tools/precision_budget.py [--episodes 8] [--style synthetic|trained] [--sites all|h,w,qkv,p,o,g]
+    python tests/studies/precision_budget.py [--episodes 8] [--style synthetic|trained] [--sites all|h,w,qkv,p,o,g]
 
 The float64 numpy/torch restatement (oracle/) is run once exactly and once per configuration with the GPU path's
 rounding emulated at the chosen sites (operands rounded to fp16 / bf16, everything else float64), and the predicted
@@ -19,7 +19,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(ROOT, "hyper-vla_amd"), ROOT):
     sys.path.insert(0, p)
 
