@@ -670,6 +670,29 @@ def test_every_stage_is_run_to_run_deterministic(full):
 
 
 @pytest.mark.gpu
+def test_two_stream_step_with_a_narrow_mlp():
+    """The two halves of a two-stream step share the workspace that first holds an episode's im2col rows [P][Kp] and later
+    its MLP hidden rows [S][F].  In the MID geometry P * Kp = 64 * 1280 > S * F = 65 * 512, so slices cut by S * F alone
+    would overlap while both halves run their patch embedding: the slices are cut by the larger of the two, and the
+    two-stream bytes equal the single-stream ones."""
+    _need_gpu()
+    from hypervla import synthetic as syn
+    from hypervla.config import MID
+    from hypervla.model import HyperVLA
+    g, B = MID, 96
+    assert g.patches * 1280 > (g.patches + 1) * g.enc_mlp
+    ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
+    outs = []
+    for streams in (1, 2):
+        m = HyperVLA.from_synthetic(g, max_batch=B, streams=streams)
+        w, tasks, _ = m.create_tasks(instruction_dict=ins, initial_state=st)
+        for _ in range(3):                                   # several steps: a race would not need to show on the first
+            a, inter = m.sample_actions(im, ins, tasks, np.ones((B, 1)), base_params=w)
+        outs.append((np.asarray(a), np.asarray(inter["gripper_logits"])))
+    np.testing.assert_array_equal(outs[1][0], outs[0][0])
+    np.testing.assert_array_equal(outs[1][1], outs[0][1])
+
+
 def test_bench_contract_with_two_ranks_on_one_gpu():
     """bench.py's N > 1 control flow (barrier, max over ranks, rank 0 prints ONE line, whole-job value) on a one-GPU box:
     two ranks share GPU 0 over gloo (test hook HVLA_BENCH_SHARE_GPU); the driver's real runs use RCCL, one rank per GPU."""
