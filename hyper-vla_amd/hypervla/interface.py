@@ -36,6 +36,24 @@ def euler2axangle(ai: float, aj: float, ak: float):
     return np.array([x, y, z]) / v, 2.0 * np.arctan2(v, w)
 
 
+def device_unnormalization(stats: dict, normalization_type: str = "normal"):
+    """(mean, std, mask) float32 / float32 / uint8 vectors for ``hvla_ensemble`` (include/hvla.h), which un-normalises with
+    ``a * std + mean`` on the masked columns: the dataset's own mean / std for NormalizationType.NORMAL
+    (data/utils/hypervla_interface.py:219-230), and for BOUNDS (:231-242) the pair that makes the same map out of
+    ``(a + 1) * (p99 - p01 + 1e-8) / 2 + p01``."""
+    if str(normalization_type).lower() in ("bounds",):
+        p01, p99 = np.asarray(stats["p01"], np.float64), np.asarray(stats["p99"], np.float64)
+        std = (p99 - p01 + 1e-8) / 2
+        mean = p01 + std
+        mask = np.asarray(stats.get("mask", np.ones_like(p01, dtype=bool)), bool)
+    elif str(normalization_type).lower() in ("normal",):
+        mean, std = np.asarray(stats["mean"], np.float64), np.asarray(stats["std"], np.float64)
+        mask = np.asarray(stats.get("mask", np.ones_like(mean, dtype=bool)), bool)
+    else:
+        raise ValueError(f"Unknown normalization type: {normalization_type}")
+    return mean.astype(np.float32), std.astype(np.float32), mask.astype(np.uint8)
+
+
 class ActionEnsembler:
     """Temporal ensemble over the last ``pred_action_horizon`` predictions; works for one episode
     ([horizon, 7] inputs) or a batch ([B, horizon, 7])."""

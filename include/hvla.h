@@ -125,7 +125,10 @@ int hvla_step(hvla_ctx* ctx, const hvla_weights* w, const uint8_t* images, float
  * episodes (data/utils/hypervla_interface.py:219-253, data/utils/action_ensemble.py:15-27,
  * temperature 0).  Keeps a device ring of the last `horizon` predictions inside `w`.
  *   actions f32 [B, horizon, action_dim] (as written by hvla_policy/step);
- *   mean/std f32 [action_dim], mask u8 [action_dim] (device); out f32 [B, action_dim].          */
+ *   mean/std f32 [action_dim], mask u8 [action_dim] (device); out f32 [B, action_dim].
+ * The un-normalisation is the affine map a * std + mean on the masked columns.  NormalizationType.NORMAL (:219-230) passes
+ * the dataset's mean / std; NormalizationType.BOUNDS (:231-242), (a + 1) (p99 - p01 + 1e-8) / 2 + p01, is the same map with
+ * std = (p99 - p01 + 1e-8) / 2 and mean = p01 + std (hypervla.interface.device_unnormalization builds either pair).  */
 int hvla_ensemble_reset(hvla_ctx* ctx, hvla_weights* w, void* stream);
 int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const float* mean,
                   const float* std, const uint8_t* mask, float* out, void* stream);

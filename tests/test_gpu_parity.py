@@ -140,6 +140,31 @@ def test_device_ensemble_matches_host(mid):
         np.testing.assert_allclose(out.cpu().numpy(), ens.ensemble_action(un), atol=1e-5)
 
 
+def test_device_ensemble_with_bounds_normalisation(mid):
+    """NormalizationType.BOUNDS (data/utils/hypervla_interface.py:231-242) through the device-side un-normalise + ensemble:
+    `device_unnormalization` turns (a + 1) (p99 - p01 + 1e-8) / 2 + p01 into the a * std + mean form hvla_ensemble computes."""
+    from hypervla.interface import ActionEnsembler, device_unnormalization
+    m, g, B = mid["model"], mid["g"], mid["B"]
+    w, _, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
+    rng = np.random.default_rng(9)
+    p01 = rng.uniform(-1.5, -0.2, g.action_dim)
+    stats = {"p01": p01, "p99": p01 + rng.uniform(0.3, 2.5, g.action_dim), "mask": np.array([True] * (g.action_dim - 1) + [False])}
+    dev = m.device
+    mean, std, mask = (torch.tensor(v, device=dev) for v in device_unnormalization(stats, "bounds"))
+    ens = ActionEnsembler(g.horizon, 0.0)
+    out = torch.empty(B, g.action_dim, device=dev)
+    m._ctx.ensemble_reset(w._h, m._stream())
+    for t in range(6):
+        a = rng.uniform(-1, 1, size=(B, g.horizon, g.action_dim)).astype(np.float32)
+        ad = torch.tensor(a, device=dev)
+        m._ctx.ensemble(w._h, ad.data_ptr(), mean.data_ptr(), std.data_ptr(), mask.data_ptr(), out.data_ptr(), m._stream())
+        a64 = a.astype(np.float64)
+        un = np.where(stats["mask"], (a64 + 1) * (stats["p99"] - stats["p01"] + 1e-8) / 2 + stats["p01"], a64)   # the reference's formula
+        np.testing.assert_allclose(out.cpu().numpy(), ens.ensemble_action(un), atol=2e-6)
+    with pytest.raises(ValueError):
+        device_unnormalization(stats, "quantile")
+
+
 def test_error_behaviour(mid):
     m = mid["model"]
     w, tasks, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])

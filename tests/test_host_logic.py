@@ -182,3 +182,18 @@ def test_gradient_buckets_tile_the_flat_vector():
             assert heads[0] == at["W_cat"] and heads[0] + heads[1] == (total if not enc else dict((n, (o, l)) for n, o, l in b)["image_encoder"][0])
     enc_bucket = gradient_buckets(FULL, True)[0]
     assert enc_bucket[2] > 85_000_000 and enc_bucket[2] * 4 > 340e6            # the 343 MB bucket that overlaps
+
+
+def test_device_unnormalization_pairs():
+    """BOUNDS as the affine pair hvla_ensemble takes: a * std + mean == (a + 1) (p99 - p01 + 1e-8) / 2 + p01."""
+    from hypervla.interface import device_unnormalization
+    rng = np.random.default_rng(1)
+    p01 = rng.uniform(-2, 0, 7)
+    stats = {"p01": p01, "p99": p01 + rng.uniform(0.1, 3, 7), "mean": rng.normal(size=7), "std": rng.uniform(0.1, 2, 7)}
+    a = rng.uniform(-1, 1, (5, 7))
+    mean, std, mask = device_unnormalization(stats, "bounds")
+    np.testing.assert_allclose(a * std + mean, (a + 1) * (stats["p99"] - stats["p01"] + 1e-8) / 2 + stats["p01"], rtol=2e-6, atol=2e-6)
+    assert mask.dtype == np.uint8 and mask.all()
+    mean, std, _ = device_unnormalization(stats, "normal")
+    np.testing.assert_allclose(mean, stats["mean"].astype(np.float32))
+    np.testing.assert_allclose(std, stats["std"].astype(np.float32))
