@@ -255,7 +255,15 @@ class HyperVLA:
         [B, horizon, action_dim]."""
         torch = _torch()
         if train:
-            raise NotImplementedError("train=True (dropout / embedding noise) is outside the inference path")
+            # train=True switches on nn.Dropout(dropout_rate) (base_vit.py:205, transformer.py:67,74,192,244) and the
+            # image_embedding_noise (base_vit.py:123-127).  Every shipped config sets all of them to 0
+            # (scripts/configs/hypervla_pretrain_config.py:333-339,376-380), where train=True is the same function as
+            # train=False; a checkpoint that really asks for noise is refused rather than silently run without it.
+            v = self.config["base_net_kwargs"]["vit_kwargs"]
+            rates = {k: float(v.get(k, 0.0) or 0.0) for k in ("dropout_rate", "attention_dropout_rate", "image_embedding_noise")}
+            rates["embedding_dropout_rate"] = float(self.config["base_net_kwargs"].get("embedding_dropout_rate", 0.0) or 0.0)
+            if any(r > 0 for r in rates.values()):
+                raise NotImplementedError(f"train=True with {rates}: dropout / embedding noise are not built (the README run uses 0)")
         if not isinstance(base_params, GeneratedWeights):
             raise TypeError("base_params must be the handle returned by create_tasks")
         g = self.geometry

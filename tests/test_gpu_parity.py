@@ -165,6 +165,22 @@ def test_device_ensemble_with_bounds_normalisation(mid):
         device_unnormalization(stats, "quantile")
 
 
+def test_train_flag_is_the_identity_at_zero_rates(mid):
+    """sample_actions(train=True) (hypervla/model.py:85-137): with dropout_rate = image_embedding_noise = 0, the values of every
+    shipped config, it is the same function; a config with a non-zero rate is refused."""
+    import copy
+    m = mid["model"]
+    w, tasks, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
+    a0, _ = m.sample_actions(mid["im"], mid["ins"], tasks, None, w)
+    a1, _ = m.sample_actions(mid["im"], mid["ins"], tasks, None, w, train=True)
+    np.testing.assert_array_equal(np.asarray(a0), np.asarray(a1))
+    noisy = copy.copy(m)
+    noisy.config = copy.deepcopy(m.config)
+    noisy.config["base_net_kwargs"]["vit_kwargs"]["image_embedding_noise"] = 0.1
+    with pytest.raises(NotImplementedError):
+        noisy.sample_actions(mid["im"], mid["ins"], tasks, None, w, train=True)
+
+
 def test_error_behaviour(mid):
     m = mid["model"]
     w, tasks, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
