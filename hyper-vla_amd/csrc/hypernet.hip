@@ -232,11 +232,18 @@ __global__ __launch_bounds__(CTX_THREADS) void ctx_encoder_kernel(CtxParams p) {
 // ------------------------------------------------------------------------------------------------
 // grid.x = ceil(ntiles / 4); each wave owns one 32-position tile and loops over all episode tiles.
 // A fragments (W_cat^T, hi/lo) live in registers for the whole loop (KS * 2 * 4 VGPRs).
+// Stores: a lane ends up with 16 consecutive packed positions of ONE episode, so written straight from registers a store
+// instruction is 64 pieces of 16 bytes in 32 different rows of the arena (rows are 356 KB apart).  Workgroups whose four
+// tiles all lie in the matrix region therefore go through LDS: the four waves park their [32 episodes x 32 positions] hi and
+// lo tiles side by side ([plane][episode][128 positions] = 16 KB), and every wave then writes eight episode rows as 256-byte
+// runs (16 lanes x 16 B per row).  The vector region (f32, 10 % of the bytes) and a ragged last workgroup keep the direct form.
 template <int KS>
 __global__ __launch_bounds__(256) void weightgen_kernel(WeightGenParams p) {
+  __shared__ __attribute__((aligned(16))) __bf16 stage[2][32][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
-  if (tile >= p.ntiles) return;
+  const bool via_lds = blockIdx.x * 4 + 3 < p.ntiles && (blockIdx.x * 4 + 4) * 32 <= p.Gm;     // workgroup-uniform
+  if (tile >= p.ntiles) return;                  // (only in a workgroup that is not via_lds: no barrier is skipped)
   const int col = lane & 31, half = lane >> 5;
   bf16x8 ah[KS], al[KS];
   {
@@ -272,7 +279,33 @@ __global__ __launch_bounds__(256) void weightgen_kernel(WeightGenParams p) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
     }
-    if (b < p.B) {
+    if (via_lds) {
+      bf16x8 h0, h1, l0, l1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 hi, lo;
+        split1(acc[j], hi, lo);
+        h0[j] = hi, l0[j] = lo;
+        split1(acc[8 + j], hi, lo);
+        h1[j] = hi, l1[j] = lo;
+      }
+      __syncthreads();                           // the previous episode tile's rows have been read
+      bf16x8* sh = reinterpret_cast<bf16x8*>(&stage[0][col][wave * 32 + half * 16]);
+      bf16x8* sl = reinterpret_cast<bf16x8*>(&stage[1][col][wave * 32 + half * 16]);
+      sh[0] = h0, sh[1] = h1, sl[0] = l0, sl[1] = l1;
+      __syncthreads();
+      const size_t gpos = (size_t)blockIdx.x * 128 + (lane & 15) * 8;          // 16 lanes x 16 B = one episode's 256-byte run
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row = wave * 8 + u * 4 + (lane >> 4);
+        if (b0 + row < p.B) {
+          const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&stage[0][row][(lane & 15) * 8]);
+          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&stage[1][row][(lane & 15) * 8]);
+          *reinterpret_cast<bf16x8*>(p.wh + (size_t)(b0 + row) * p.Gm + gpos) = vh;
+          *reinterpret_cast<bf16x8*>(p.wl + (size_t)(b0 + row) * p.Gm + gpos) = vl;
+        }
+      }
+    } else if (b < p.B) {
       if (pos0 < p.Gm) {
         bf16x8 h0, h1, l0, l1;
 #pragma unroll
