@@ -20,7 +20,7 @@ namespace hvla {
 // ------------------------------------------------------------------------------------------------
 // context encoder
 // ------------------------------------------------------------------------------------------------
-constexpr int CTX_THREADS = 256;
+constexpr int CTX_THREADS = 1024;   // 16 waves: one workgroup (one episode) per CU, so the waves of that one workgroup have to hide each other's latencies
 constexpr int CTX_RG = 20;   // max rows per row-group (S <= 40)
 
 // y[s][n] (+)= sum_k xs[s][k] * W[k][n]   for s in [0,S), n in [0,N); xs in LDS (row stride xs_ld),
@@ -28,8 +28,12 @@ constexpr int CTX_RG = 20;   // max rows per row-group (S <= 40)
 template <typename Sink>
 __device__ __forceinline__ void dense_rows(const float* __restrict__ xs, int xs_ld, int S, int K,
                                            const float* __restrict__ W, int N, Sink sink) {
-  const int rg = (S + 1) / 2;                 // two row groups
-  const int items = 2 * N;
+  // the S rows are cut into nrg row groups, as many as there are threads for (at least two: CTX_RG rows per thread at most);
+  // an output element is one thread's k = 0 .. K-1 chain whatever the grouping, so the bits do not depend on it
+  int nrg = CTX_THREADS / N;
+  if (nrg < 2) nrg = 2;
+  const int rg = (S + nrg - 1) / nrg;
+  const int items = nrg * N;
   for (int it = threadIdx.x; it < items; it += CTX_THREADS) {
     const int n = it % N, g0 = (it / N) * rg;
     float acc[CTX_RG];
@@ -40,10 +44,12 @@ __device__ __forceinline__ void dense_rows(const float* __restrict__ xs, int xs_
       const float w2 = W[(size_t)(k + 2) * N + n], w3 = W[(size_t)(k + 3) * N + n];
 #pragma unroll
       for (int r = 0; r < CTX_RG; ++r) {
-        int row = g0 + r;
-        row = row < S ? row : S - 1;          // clamp: discarded at the sink
-        const f32x4 x = *reinterpret_cast<const f32x4*>(xs + row * xs_ld + k);
-        acc[r] = fmaf(x[0], w0, fmaf(x[1], w1, fmaf(x[2], w2, fmaf(x[3], w3, acc[r]))));
+        if (r < rg) {                          // uniform
+          int row = g0 + r;
+          row = row < S ? row : S - 1;          // clamp: discarded at the sink
+          const f32x4 x = *reinterpret_cast<const f32x4*>(xs + row * xs_ld + k);
+          acc[r] = fmaf(x[0], w0, fmaf(x[1], w1, fmaf(x[2], w2, fmaf(x[3], w3, acc[r]))));
+        }
       }
     }
 #pragma unroll
@@ -90,10 +96,10 @@ __global__ __launch_bounds__(CTX_THREADS) void ctx_encoder_kernel(CtxParams p) {
     const float* tok = p.tok + (size_t)b * T * p.lang_dim;
     // stage the token rows in K-chunks of `kc` through `big`
     const int kc = 128, ldt = kc + 4;
-    const int rg = (T + 1) / 2;
+    const int nrg = CTX_THREADS / C, rg = (T + nrg - 1) / nrg;       // C divides CTX_THREADS (128, 64, 32)
     float acc[CTX_RG];
     const int n = threadIdx.x % C, g0 = (threadIdx.x / C) * rg;
-    const bool active = threadIdx.x < 2 * C;
+    const bool active = threadIdx.x < nrg * C;
 #pragma unroll
     for (int r = 0; r < CTX_RG; ++r) acc[r] = 0.f;
     for (int k0 = 0; k0 < p.lang_dim; k0 += kc) {
@@ -110,10 +116,12 @@ __global__ __launch_bounds__(CTX_THREADS) void ctx_encoder_kernel(CtxParams p) {
           const float w0 = W[0], w1 = W[C], w2 = W[2 * C], w3 = W[3 * C];
 #pragma unroll
           for (int r = 0; r < CTX_RG; ++r) {
-            int row = g0 + r;
-            row = row < T ? row : T - 1;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(big + row * ldt + k);
-            acc[r] = fmaf(xv[0], w0, fmaf(xv[1], w1, fmaf(xv[2], w2, fmaf(xv[3], w3, acc[r]))));
+            if (r < rg) {                                            // uniform
+              int row = g0 + r;
+              row = row < T ? row : T - 1;
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(big + row * ldt + k);
+              acc[r] = fmaf(xv[0], w0, fmaf(xv[1], w1, fmaf(xv[2], w2, fmaf(xv[3], w3, acc[r]))));
+            }
           }
         }
       }

@@ -743,9 +743,13 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HVLA_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    import socket
     for extra in ([], ["--finetune"]):
+        with socket.socket() as sk:                          # a fresh port per launch: the previous one may still be in TIME_WAIT
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                "--batch", "8", "--no-cpu-baseline"] + extra
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -436,8 +436,12 @@ def test_data_parallel_step_equals_the_big_batch_step(tmp_path):
     from hypervla.config import MID
     from hypervla.model import HyperVLA
     from hypervla.train import FineTuner
+    import socket
     out = str(tmp_path / "rank0.npy")
-    mp.spawn(_dp_worker, args=(2, 29533, out), nprocs=2, join=True)
+    with socket.socket() as sk:                              # a free port, not a fixed one another run may still hold
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
     g, total = MID, 4
     model = HyperVLA.from_synthetic(g, max_batch=total)
     ins, st, im = syn.synthetic_instructions(total, g), syn.synthetic_initial_state(total, g), syn.synthetic_images(total, g)
