@@ -679,6 +679,34 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 #undef HVLA_BAR
 }
 
+// 16-lane row reductions by DPP (quad swaps, then the half-row and row mirrors) and an SGPR broadcast of one lane
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  return fmaxf(v, dpp_mov<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  return v + dpp_mov<0x140>(v);
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// sum over all 64 lanes, the same value in every lane: DPP inside the four 16-lane rows, then the four row sums through
+// SGPRs -- about a hundred cycles of dependent latency instead of six ds_bpermute round trips
+__device__ __forceinline__ float wave64_sum(float v) {
+  const float t = row16_sum(v);
+  return (lane_bcast(t, 0) + lane_bcast(t, 16)) + (lane_bcast(t, 32) + lane_bcast(t, 48));
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row of E f32 (E % 4 == 0, E <= 1024); FINAL drops row 0 of every image and
 // writes f32.
@@ -779,8 +807,7 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = wave64_sum(sum);
     const float mean = sum / E;
     float sq = 0.f;
 #pragma unroll
@@ -793,8 +820,7 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __
         }
       }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    sq = wave64_sum(sq);
     const float rstd = rsqrtf(sq / E + 1e-6f);
     typename Op::elem* orow = out + ((size_t)b * S + row) * E;
 #pragma unroll
@@ -848,27 +874,6 @@ __device__ __forceinline__ X8 tr_read2(const void* p0, const void* p1) {
   typedef short s8 __attribute__((ext_vector_type(8)));
   const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   return __builtin_bit_cast(X8, v);
-}
-
-// 16-lane row reductions by DPP (quad swaps, then the half-row and row mirrors) and an SGPR broadcast of one lane
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x141>(v));
-  return fmaxf(v, dpp_mov<0x140>(v));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_mov<0xB1>(v);
-  v += dpp_mov<0x4E>(v);
-  v += dpp_mov<0x141>(v);
-  return v + dpp_mov<0x140>(v);
-}
-__device__ __forceinline__ float lane_bcast(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
 // omean (nullable): [B][E] 16-bit mean over all S tokens of the image of the output, the operand of the out-projection's
