@@ -130,6 +130,27 @@ def finetune_bench(a, model, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def kfd_gpu_count(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process would see, counted WITHOUT the HIP runtime (torch.cuda.device_count() falls back to
+    hipGetDeviceCount() when amdsmi is unavailable, which initialises HSA in the launcher): KFD topology nodes with SIMDs,
+    cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None if sysfs is not readable (the
+    ranks then fail with their own message)."""
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` typed directly (no launcher): start one rank per GPU as children of this process,
     which has not touched the GPU (no HIP call yet; a process that has must never exec or fork GPU work), let rank 0's
@@ -137,8 +158,8 @@ def self_launch(n):
     import socket
     import subprocess
     if os.environ.get("HVLA_BENCH_SHARE_GPU") != "1":
-        have = torch.cuda.device_count()             # counting devices does not initialise the GPU
-        if have < n:
+        have = kfd_gpu_count()                       # sysfs only: no HIP / HSA call in this process
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
             return 2
     with socket.socket() as s:                       # a free rendezvous port on the loopback interface
@@ -342,6 +363,8 @@ def main():
         "roofline": {"bound": "mfma", "kernel": ("gemm64_kernel" if rows <= 2047 else "gemm256p_kernel") + f"<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",
                      "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_source": (f"committed rocprofv3 --pmc passes of this command (profiles/{PMC_ROUND}_pmc_fetch_size_by_kernel.csv, "
+                                        f"{PMC_ROUND}_pmc_write_size_by_kernel.csv); NOT measured in this run") if traffic is not None else None,
                      "traffic_unit": "bytes/launch (HBM-side, PMC: 2*FETCH_SIZE+WRITE_SIZE; algorithmic 510 MB)",
                      "launch_ms": round(dom_ms, 4), "launches_timed": dom[1],
                      "flops_per_launch": fc1_flops, "rows_per_launch": main_rows, "rows_total": rows},

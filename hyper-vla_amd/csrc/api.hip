@@ -611,8 +611,13 @@ int hvla_train_step(hvla_ctx* ctx, const hvla_train_buffers* buf, const float* t
   for (hipEvent_t& e : ctx->ev_bucket)
     if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(ctx, train_step(ctx->g, L, to_tb(buf), in, B, hp, reinterpret_cast<hipStream_t>(stream), hp.forward_only ? nullptr : ctx->ev_bucket));
-  ctx->bucket_recorded[0] = !hp.forward_only && images != nullptr;
-  ctx->bucket_recorded[1] = ctx->bucket_recorded[2] = !hp.forward_only;
+  // ONE pending backward per ctx: the bucket events belong to the last hvla_train_step that ran a backward pass, and
+  // hvla_train_wait_bucket refers to that step.  A forward-only step (evaluation between a step and its apply) records
+  // nothing and leaves the pending step's events alone.
+  if (!hp.forward_only) {
+    ctx->bucket_recorded[0] = images != nullptr;
+    ctx->bucket_recorded[1] = ctx->bucket_recorded[2] = true;
+  }
   return HVLA_OK;
 }
 

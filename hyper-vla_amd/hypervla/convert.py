@@ -91,7 +91,10 @@ def _unchunk(tree):
         if tree.get("__msgpack_chunked_array__"):
             chunks = [tree["chunks"][str(i)] if isinstance(tree["chunks"], dict) else tree["chunks"][i]
                       for i in range(len(tree["chunks"]))]
-            return np.concatenate([np.asarray(c).reshape(-1) for c in chunks]).reshape(tree["shape"])
+            shape = tree["shape"]                       # flax writes tuples through _tuple_to_dict: {"0": d0, "1": d1, ...}
+            if isinstance(shape, dict):
+                shape = tuple(int(shape[str(i)]) for i in range(len(shape)))
+            return np.concatenate([np.asarray(c).reshape(-1) for c in chunks]).reshape(shape)
         return {k: _unchunk(v) for k, v in tree.items()}
     return tree
 
@@ -327,7 +330,13 @@ def convert_checkpoint(src_dir: str, dst_dir: str, step: int, ema: Optional[floa
     """Reference run directory -> a directory `HyperVLA.load_pretrained` reads.
 
     Parameters come from `tree` when given (a host-side flax tree), else from ``<src_dir>/<step>/EMA_params.pkl``.
-    ``config.json`` and ``dataset_statistics.json`` are copied as they are (`hypervla/model.py:260-284`)."""
+    ``dataset_statistics.json`` and ``example_batch.msgpack`` are copied as they are (`hypervla/model.py:260-284`);
+    ``config.json`` is written with the `action_head_kwargs` defaults of `hypervla/model.py:157-163` filled in and, when the
+    position table was resized, the key `position_embeddings_baked_from`.  Converting in place would overwrite the
+    reference run's own ``config.json`` with that augmented one, so `dst_dir` must differ from `src_dir`."""
+    if os.path.abspath(src_dir) == os.path.abspath(dst_dir):
+        raise ValueError("convert_checkpoint: dst_dir must not be the reference run directory itself "
+                         "(its config.json would be overwritten)")
     with open(os.path.join(src_dir, "config.json")) as f:
         config = json.load(f)
     if "action_head_kwargs" not in config["base_net_kwargs"]:            # hypervla/model.py:157-163
@@ -344,7 +353,7 @@ def convert_checkpoint(src_dir: str, dst_dir: str, step: int, ema: Optional[floa
     np.savez(out, **params)
     for name in ("dataset_statistics.json", "example_batch.msgpack"):
         sp = os.path.join(src_dir, name)
-        if os.path.exists(sp) and os.path.abspath(src_dir) != os.path.abspath(dst_dir):
+        if os.path.exists(sp):
             shutil.copyfile(sp, os.path.join(dst_dir, name))
     # the reference keeps HF's 37 x 37 DINOv2 position table and resizes it inside every forward pass; here it is baked to
     # the run-time grid once.  The config says so: FineTuner refuses to train a baked table unless told to

@@ -115,14 +115,21 @@ def lr_rsqrt(step: int, peak: float, warmup: int = 2000, timescale: int = 10000,
 
 
 def weight_decay_mask(g: Geometry, strategy: str, train_encoder: bool = False) -> np.ndarray:
-    """uint8 [n_params]: where `create_optimizer`'s decoupled weight decay applies (octo/utils/train_utils.py:330-375).
+    """uint8 [n_params]: where `create_optimizer`'s decoupled weight decay applies (octo/utils/train_utils.py:325-382).
+    The reference tests `jax.tree_util.keystr(path)` of every leaf of the hypernetwork's parameter tree; an output head is
+    the module `output_head_<flat base-net leaf name>` (hypervla/model.py:342) with leaves `kernel` and `bias`, so the
+    NAME of the generated leaf is part of the path of both.
 
-    "v5" (the README run, README.md:29): the output heads that generate base-net *kernel* leaves (head kernel and head
-    bias alike: the test is on the head's name), nothing else of the hypernetwork, and EVERY leaf of the shared image
-    encoder.  "v1" (the config default, hypervla_pretrain_config.py:290): every parameter whose path contains "kernel"
-    -- all Dense kernels of the hypernetwork including every output head's, and the encoder leaves named *kernel*."""
-    if strategy not in ("v1", "v5"):
-        raise ValueError(f"weight_decay_strategy {strategy!r}: 'v1' and 'v5' are built (v2/v3/v4 are not)")
+    "v1" (the config default, hypervla_pretrain_config.py:290; train_utils.py:378-382): `"kernel" in keystr(path)` -- every
+    Dense kernel of the hypernetwork, every output head's kernel, the BIAS of every head that generates a base-net
+    *kernel* leaf (its path contains `..._kernel`), and the encoder leaves named *kernel*.
+    "v2" (:326-330): everything except leaves with "norm" in the path that are not output heads.
+    "v3" (:335-350): output heads that generate *kernel* leaves (kernel and bias), every leaf of the shared image
+    encoder, and the remaining *kernel* leaves (context encoder, projections).
+    "v5" (the README run, README.md:29; :354-363): as v3 without the context-encoder kernels.
+    "v4" adds a second backward pass through a weight-decay loss (scripts/train.py:473-480) and is not built."""
+    if strategy not in ("v1", "v2", "v3", "v5"):
+        raise ValueError(f"weight_decay_strategy {strategy!r}: 'v1', 'v2', 'v3' and 'v5' are built (v4 is not)")
     layout, total = train_param_layout(g, train_encoder)
     leaves = generated_leaves(g)
     G = leaves[-1].offset + leaves[-1].size
@@ -134,12 +141,19 @@ def weight_decay_mask(g: Geometry, strategy: str, train_encoder: bool = False) -
     for name, off, shape in layout:
         n = int(np.prod(shape))
         if name == "W_cat":                       # [C, G]: the kernels of the 73 output heads
-            mask[off:off + n] = np.tile(cols, shape[0]) if strategy == "v5" else 1
-        elif name == "b_cat":                     # their biases
-            mask[off:off + n] = cols if strategy == "v5" else 0
+            mask[off:off + n] = 1 if strategy in ("v1", "v2") else np.tile(cols, shape[0])
+        elif name == "b_cat":                     # their biases: `output_head_<..._kernel>/bias` contains "kernel"
+            mask[off:off + n] = 1 if strategy == "v2" else cols
         elif name.startswith("encoder_image_encoder_"):
-            mask[off:off + n] = 1 if (strategy == "v5" or "kernel" in name) else 0
-        elif strategy == "v1" and "kernel" in name:
+            if strategy == "v1":
+                mask[off:off + n] = 1 if "kernel" in name else 0
+            elif strategy == "v2":
+                mask[off:off + n] = 0 if "norm" in name.lower() else 1
+            else:
+                mask[off:off + n] = 1
+        elif strategy == "v2":
+            mask[off:off + n] = 0 if "norm" in name.lower() else 1
+        elif strategy in ("v1", "v3") and "kernel" in name:
             mask[off:off + n] = 1
     return mask
 

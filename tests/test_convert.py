@@ -219,3 +219,26 @@ def test_example_batch_msgpack_without_flax(tmp_path):
     # bfloat16 leaves (not a numpy dtype) come back as float32
     bf = msgpack_restore(bytes.fromhex("81a162" "c7" "10" "01" "93" "91" "01" "a8" + "bfloat16".encode().hex() + "c4" "02" "803f"))
     assert bf["b"].dtype == np.float32 and bf["b"].tolist() == [1.0]
+
+
+def test_chunked_array_map_and_in_place_conversion(tmp_path):
+    """Arrays above flax's chunk size are written as a map {"__msgpack_chunked_array__": True, "shape": {"0": d0, ...},
+    "chunks": {"0": c0, ...}} (flax/serialization.py `_chunk`, tuples go through `_tuple_to_dict`); and converting a run
+    directory onto itself is refused (it would overwrite the reference's config.json)."""
+    import msgpack
+    from hypervla.convert import _EXT_NDARRAY, convert_checkpoint, msgpack_restore
+    a = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    flat = a.reshape(-1)
+
+    def nd(x):
+        return msgpack.ExtType(_EXT_NDARRAY, msgpack.packb((list(x.shape), x.dtype.name, x.tobytes()), use_bin_type=True))
+
+    wire = msgpack.packb({"w": {"__msgpack_chunked_array__": True, "shape": {"0": 2, "1": 3, "2": 4},
+                                "chunks": {"0": nd(flat[:10]), "1": nd(flat[10:20]), "2": nd(flat[20:])}}}, use_bin_type=True)
+    np.testing.assert_array_equal(msgpack_restore(wire)["w"], a)
+    wire_list = msgpack.packb({"w": {"__msgpack_chunked_array__": True, "shape": [2, 3, 4],
+                                     "chunks": [nd(flat[:12]), nd(flat[12:])]}}, use_bin_type=True)
+    np.testing.assert_array_equal(msgpack_restore(wire_list)["w"], a)
+    (tmp_path / "config.json").write_text("{}")
+    with pytest.raises(ValueError, match="dst_dir"):
+        convert_checkpoint(str(tmp_path), str(tmp_path), 1)

@@ -207,7 +207,8 @@ def test_encoder_gradients_full_geometry():
 def test_two_group_optimizer_and_delta_decay(strategy):
     """multi_transform{generated: AdamW(lr, mask), shared: AdamW(base_lr, mask)} under one global-norm clip, plus the pull
     towards the pretrained encoder (train_utils.py:330-426, scripts/train.py:465-471), for both weight-decay strategies:
-    v5 (README run) decays the kernel-generating output heads and EVERY image-encoder leaf, v1 every *kernel* parameter.
+    v5 (README run) decays the kernel-generating output heads and EVERY image-encoder leaf, v1 every leaf whose path
+    contains "kernel" (which includes the bias of a head that generates a kernel).
     Under v5 with base_weight_decay > 0 a shared bias / norm / LayerScale leaf that sits at its pretrained value sees
     +wd p - wd p0 = 0, i.e. it does not drift."""
     from hypervla import synthetic as syn
@@ -247,7 +248,9 @@ def test_two_group_optimizer_and_delta_decay(strategy):
             if strategy == "v5":
                 m = np.tile(cols, shape[0]) if name == "W_cat" else cols if name == "b_cat" else np.zeros(n, bool)
             else:
-                m = np.ones(n, bool) if (name == "W_cat" or "kernel" in name) else np.zeros(n, bool)
+                # v1: "kernel" in keystr(path) (train_utils.py:378-382); the path of a head's bias is
+                # ['output_head_<leaf>']['bias'], which contains "kernel" when the generated leaf is a kernel
+                m = np.ones(n, bool) if (name == "W_cat" or "kernel" in name) else cols if name == "b_cat" else np.zeros(n, bool)
             want[sl] = p0[sl] - lr * (upd[sl] + wd * p0[sl] * m)
         else:
             k = 1.0 if (strategy == "v5" or "kernel" in name) else 0.0

@@ -138,30 +138,49 @@ def test_batched_ensembler_equals_unbatched():
 
 
 def test_weight_decay_masks_follow_the_reference_strategies():
-    """octo/utils/train_utils.py:330-375: v5 = output heads that generate base-net kernels + every image-encoder leaf; v1 =
-    every parameter whose path contains "kernel"."""
+    """octo/utils/train_utils.py:325-382.  The reference's mask functions look at `jax.tree_util.keystr(path)` of every leaf
+    of the hypernetwork's parameter tree and, for v3 / v5, at the top-level key `path[0].key`.  Here every leaf of the
+    checkpoint schema gets its key path back ("output_head_<leaf>/bias" -> ["output_head_<leaf>", "bias"]), the four
+    predicates are evaluated on it as the reference writes them, and the flat mask is compared slice by slice."""
     from hypervla.config import MID, generated_leaves
-    from hypervla.train import train_param_layout, weight_decay_mask
+    from hypervla.train import train_param_layout, unpack_params, weight_decay_mask
     g = MID
     layout, total = train_param_layout(g, True)
-    v5, v1 = weight_decay_mask(g, "v5", True), weight_decay_mask(g, "v1", True)
-    assert v5.shape == v1.shape == (total,)
-    leaves = generated_leaves(g)
-    G = leaves[-1].offset + leaves[-1].size
-    kernel_cols = sum(l.size for l in leaves if "kernel" in l.flat_name)
-    for name, off, shape in layout:
-        n = int(np.prod(shape))
-        a, b = v5[off:off + n], v1[off:off + n]
-        if name == "W_cat":
-            assert a.sum() == shape[0] * kernel_cols and b.all()
-        elif name == "b_cat":
-            assert a.sum() == kernel_cols and not b.any()
-        elif name.startswith("encoder_image_encoder_"):
-            assert a.all() and bool(b.all()) == ("kernel" in name) and (b.all() or not b.any())
-        else:                                           # context encoder / projections / position embeddings
-            assert not a.any() and bool(b.all()) == ("kernel" in name)
-    with pytest.raises(ValueError):
-        weight_decay_mask(g, "v3")
+
+    def keystr(keys):                                                   # jax.tree_util.keystr of DictKeys
+        return "".join(f"['{k}']" for k in keys)
+
+    def v1(keys):                                                       # :378-382
+        return "kernel" in keystr(keys)
+
+    def v2(keys):                                                       # :326-330
+        ps = keystr(keys)
+        return not ("norm" in ps.lower() and "output_head" not in ps)
+
+    def v3(keys):                                                       # :335-350
+        if "output_head" in keys[0]:
+            return "kernel" in keys[0]
+        return "image_encoder" in keystr(keys) or "kernel" in keystr(keys)
+
+    def v5(keys):                                                       # :354-363
+        if "output_head" in keys[0]:
+            return "kernel" in keys[0]
+        return "image_encoder" in keystr(keys)
+
+    for strategy, pred in (("v1", v1), ("v2", v2), ("v3", v3), ("v5", v5)):
+        mask = weight_decay_mask(g, strategy, True)
+        assert mask.shape == (total,) and mask.dtype == np.uint8
+        named = unpack_params(g, mask, True)                            # reference-named tensors of 0 / 1
+        assert len(named) > 100
+        for name, m in named.items():
+            want = pred(name.split("/"))
+            assert m.size and bool(m.all()) == want and (m.all() or not m.any()), (strategy, name, want)
+    # the case the v1 mask is easy to get wrong on: the bias of a head that generates a base-net kernel is decayed
+    lf = next(l for l in generated_leaves(g) if "kernel" in l.flat_name)
+    assert unpack_params(g, weight_decay_mask(g, "v1", True), True)[lf.head_name + "/bias"].all()
+    for bad in ("v4", "v6"):
+        with pytest.raises(ValueError):
+            weight_decay_mask(g, bad)
 
 
 def test_gradient_buckets_tile_the_flat_vector():

@@ -88,4 +88,24 @@ def test_bench_self_launch_builds_the_launcher_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     monkeypatch.delenv("HVLA_BENCH_SHARE_GPU")
     seen.clear()
-    assert bench.self_launch(8) == 2 and not seen          # this container exposes no GPU: refused, nothing spawned
+    monkeypatch.setattr(bench, "kfd_gpu_count", lambda: 4)
+    assert bench.self_launch(8) == 2 and not seen          # fewer GPUs than asked for: refused, nothing spawned
+    monkeypatch.setattr(bench, "kfd_gpu_count", lambda: None)
+    assert bench.self_launch(8) == 7 and seen              # sysfs unreadable: the ranks report the problem themselves
+
+
+def test_gpu_count_comes_from_sysfs_not_from_hip(tmp_path, monkeypatch):
+    """The launcher parent must not initialise HIP: GPUs are KFD topology nodes with SIMDs, cut down by the
+    *_VISIBLE_DEVICES variables."""
+    import importlib
+    bench = importlib.import_module("bench")
+    for i, simd in enumerate((0, 1024, 1024, 1024)):          # node 0 is the CPU
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.kfd_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.kfd_gpu_count(str(tmp_path)) == 2
+    assert bench.kfd_gpu_count(str(tmp_path / "absent")) is None
