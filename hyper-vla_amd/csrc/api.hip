@@ -64,9 +64,14 @@ struct hvla_ctx {
   // cfg.streams == 2: helper stream and fork / join events of hvla_step
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // weight arenas handed back with hvla_weights_free wait here for the next hvla_generate of the same batch size: after
+  // the first episode batch hvla_generate does not allocate (include/hvla.h: it can then be captured / does not sync)
+  std::vector<hvla_weights*> arena_pool;
+  static constexpr size_t ARENA_POOL_MAX = 4;
   hipEvent_t ev_bucket[3] = {nullptr, nullptr, nullptr};   // hvla_train_step: gradient buckets final (created on first use)
   bool bucket_recorded[3] = {false, false, false};
   ~hvla_ctx() {
+    for (hvla_weights* w : arena_pool) delete w;
     for (hipEvent_t e : ev_bucket)
       if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -388,14 +393,31 @@ int hvla_generate(hvla_ctx* ctx, const float* tok, const int64_t* mask, const fl
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const PolicyLayout& pl = ctx->lay.pl;
   const Geom& g = ctx->g;
-  std::unique_ptr<hvla_weights> w(new hvla_weights);
-  w->B = B;
-  hipError_t e = hipSuccess;
-  auto A = [&](DevBuf& b, size_t n) { if (e == hipSuccess) e = b.alloc(n); };
-  A(w->wh, (size_t)B * pl.Gm * 2); A(w->wl, (size_t)B * pl.Gm * 2); A(w->vf, (size_t)B * pl.Gv * 4);
-  A(w->ctx, (size_t)B * g.C * 4);
-  A(w->ring, (size_t)g.horizon * B * g.horizon * g.action_dim * 4); A(w->count, 16);
-  if (e != hipSuccess) FAIL(ctx, HVLA_E_ARENA_FULL, "weight arena for %d episodes: %s", B, hipGetErrorString(e));
+  std::unique_ptr<hvla_weights> w;
+  for (size_t i = 0; i < ctx->arena_pool.size(); ++i)          // an arena of this batch size handed back earlier
+    if (ctx->arena_pool[i]->B == B) {
+      w.reset(ctx->arena_pool[i]);
+      ctx->arena_pool.erase(ctx->arena_pool.begin() + i);
+      break;
+    }
+  if (!w) {
+    w.reset(new hvla_weights);
+    w->B = B;
+    hipError_t e = hipSuccess;
+    auto A = [&](DevBuf& b, size_t n) { if (e == hipSuccess) e = b.alloc(n); };
+    A(w->wh, (size_t)B * pl.Gm * 2); A(w->wl, (size_t)B * pl.Gm * 2); A(w->vf, (size_t)B * pl.Gv * 4);
+    A(w->ctx, (size_t)B * g.C * 4);
+    A(w->ring, (size_t)g.horizon * B * g.horizon * g.action_dim * 4); A(w->count, 16);
+    if (e != hipSuccess) {
+      for (hvla_weights* q : ctx->arena_pool) delete q;        // give the pooled arenas back to the device and retry once
+      ctx->arena_pool.clear();
+      e = hipSuccess;
+      A(w->wh, (size_t)B * pl.Gm * 2); A(w->wl, (size_t)B * pl.Gm * 2); A(w->vf, (size_t)B * pl.Gv * 4);
+      A(w->ctx, (size_t)B * g.C * 4);
+      A(w->ring, (size_t)g.horizon * B * g.horizon * g.action_dim * 4); A(w->count, 16);
+    }
+    if (e != hipSuccess) FAIL(ctx, HVLA_E_ARENA_FULL, "weight arena for %d episodes: %s", B, hipGetErrorString(e));
+  }
   HIPCHK(ctx, hipMemsetAsync(w->count.p, 0, 16, st));
   CtxParams cp = ctx->ctxp;
   cp.tok = tok; cp.attn_mask = mask; cp.cls = cls;
@@ -411,8 +433,13 @@ int hvla_generate(hvla_ctx* ctx, const float* tok, const int64_t* mask, const fl
 
 int hvla_weights_free(hvla_ctx* ctx, hvla_weights* w) {
   if (!w) return HVLA_OK;
-  if (ctx) (void)hipSetDevice(ctx->device);
-  delete w;
+  if (!ctx) { delete w; return HVLA_OK; }
+  (void)hipSetDevice(ctx->device);
+  // hipFree waited for the device; a pooled arena must give the same guarantee before another stream's hvla_generate
+  // writes into it (this call has no stream of its own: frees happen at episode resets, not in the step loop)
+  (void)hipDeviceSynchronize();
+  if (ctx->arena_pool.size() < hvla_ctx::ARENA_POOL_MAX) ctx->arena_pool.push_back(w);
+  else delete w;
   return HVLA_OK;
 }
 

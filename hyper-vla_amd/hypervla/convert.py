@@ -244,6 +244,25 @@ def bake_position_embeddings(table: np.ndarray, grid: int) -> np.ndarray:
     return np.concatenate([table[:, :1], out.reshape(1, grid * grid, E)], axis=1)
 
 
+def tree_from_params(params: Mapping[str, np.ndarray]) -> Dict[str, Any]:
+    """Inverse of :func:`params_from_tree`: the flat '/'-named dict -> the nested hypernetwork parameter tree of the
+    reference (`HyperVLA.params`, hypervla/model.py:330-346): modules nest by '/', the shared image-encoder leaves are flat
+    vectors under their one-level names `encoder_image_encoder_<path>`.  Values keep their shapes (the shared leaves are
+    ravelled); reshape against the target tree's leaves where the reference's shapes are at hand
+    (tools/make_reference_fixtures.py does)."""
+    tree: Dict[str, Any] = {}
+    for name, v in params.items():
+        v = np.asarray(v, np.float32)
+        if name.startswith("encoder_image_encoder_"):
+            v = v.reshape(-1)
+        node = tree
+        keys = name.split("/")
+        for k in keys[:-1]:
+            node = node.setdefault(k, {})
+        node[keys[-1]] = v
+    return tree
+
+
 # ------------------------------------------------------------------------------------------------ HF torch DINOv2 -> shared leaves
 def dinov2_from_hf_state_dict(sd: Mapping[str, Any], g: Geometry) -> Dict[str, np.ndarray]:
     """``Dinov2Model.state_dict()`` (torch layout) -> the checkpoint's shared leaves: flat float32 vectors named

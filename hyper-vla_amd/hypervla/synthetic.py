@@ -261,3 +261,25 @@ def synthetic_token_ids(batch: int, t: T5Geometry = T5_BASE, tokens: int = 32, r
     ids = ids * mask
     ids[np.arange(batch), n - 1] = 1
     return {"input_ids": ids, "attention_mask": mask}
+
+
+# ------------------------------------------------------------------------------------------------ reference pin (tools/make_reference_fixtures.py)
+SEED_POS37 = 5100
+
+
+def synthetic_position_table_hub(g: Geometry = FULL, n: int = 37, seed: int = SEED_POS37) -> np.ndarray:
+    """A position table of the SHAPE the reference's DINOv2 module declares -- [1, 1 + 37*37, E], the hub config's
+    image_size 518 / patch 14 (hypervla/components/base_vit.py:76-77) -- which `FlaxDinov2Embeddings` resizes to the
+    16 x 16 grid inside every forward pass.  Seeded, never stored: the reference runs on this table
+    (tools/make_reference_fixtures.py) and this build on `convert.bake_position_embeddings` of it."""
+    return _rng(seed).normal(0.0, 0.02, size=(1, 1 + n * n, g.enc_dim)).astype(np.float32)
+
+
+def synthetic_params_for_reference_pin(g: Geometry = FULL) -> Dict[str, np.ndarray]:
+    """`synthetic_params(g)` with the DINOv2 position table replaced by the hub-shaped one baked to this geometry's grid:
+    the parameters the HIP path / the oracle run on when they are compared with tests/golden/reference_full_b4.npz."""
+    from .convert import bake_position_embeddings
+    P = dict(synthetic_params(g))
+    key = next(k for k in P if k.endswith("embeddings_position_embeddings"))
+    P[key] = bake_position_embeddings(synthetic_position_table_hub(g), g.image_size // g.patch).reshape(-1).astype(np.float32)
+    return P

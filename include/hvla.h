@@ -14,8 +14,11 @@
  *   - every call returns HVLA_OK (0) or a negative HVLA_E_* code; no C++ exception crosses the
  *     boundary; hvla_last_error(ctx) gives the message of the last failing call on that ctx.
  *   - a ctx is bound to one device; calls on one ctx are not re-entrant; different ctxs are
- *     independent.  After hvla_load_weights, generate/encode/policy/step do not allocate, do not
+ *     independent.  After hvla_load_weights, encode/policy/step do not allocate, do not
  *     synchronise and launch only on `stream`, so a step can be captured into a hipGraph.
+ *     hvla_generate allocates its weight arena only when the ctx holds no arena of that batch size
+ *     handed back by hvla_weights_free (the first episode batch of a size; afterwards it only
+ *     launches on `stream`); hvla_weights_free waits for the device, as hipFree would.
  */
 #ifndef HVLA_H_
 #define HVLA_H_

@@ -192,6 +192,23 @@ def test_error_behaviour(mid):
         m.create_tasks(instruction_dict=big, initial_state={"patch_embeddings": np.repeat(mid["st"]["patch_embeddings"], 4, 0)})
 
 
+def test_generate_reuses_the_arena_of_the_previous_episode_batch(mid):
+    """include/hvla.h: hvla_generate allocates only when the ctx holds no arena of that batch size; an arena handed back by
+    hvla_weights_free (episode reset) is reused, with the same generated parameters and no growth of device memory."""
+    m = mid["model"]
+    w, _, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
+    first = w.export()[0].clone()
+    del w
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        w, _, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
+        assert torch.equal(w.export()[0], first)
+        del w
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)
+
+
 # ------------------------------------------------------------------------------------------ full geometry
 @pytest.fixture(scope="module")
 def full(golden_dir):
