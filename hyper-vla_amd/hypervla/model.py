@@ -125,7 +125,41 @@ class HyperVLA:
         with np.load(os.path.join(checkpoint_path, cands[-1])) as z:
             params = {k: z[k] for k in z.files}
         from .convert import load_example_batch
-        return cls(config, params, load_example_batch(checkpoint_path), stats, **kw)
+        model = cls(config, params, load_example_batch(checkpoint_path), stats, **kw)
+        model.audit_operand_range()            # a real checkpoint's activations must fit the 16-bit operand type
+        return model
+
+    FP16_OPERAND_LIMIT = 32768.0               # half of fp16's largest finite value (65504)
+
+    def audit_operand_range(self, images=None):
+        """Run the image encoder once with a range audit of every 16-bit MFMA operand it writes (LayerNorm outputs, q / k /
+        v, attention outputs, GELU outputs, all layers: `hvla_encode_audit`) and refuse a checkpoint whose activations leave
+        the operand type's range: a trained DINOv2 carries outlier channels that the synthetic weights do not (DESIGN.md
+        section 2).  `images` defaults to the checkpoint's example batch; returns {site: largest |operand|}, or None when
+        there is nothing to audit on."""
+        torch = _torch()
+        if images is None:
+            try:
+                images = np.asarray(self.example_batch["observation"]["image_primary"])
+            except (TypeError, KeyError):
+                return None
+        img = self._dev(images, torch.uint8)
+        if img.dim() == 5:
+            img = img[:, 0].contiguous()
+        g = self.geometry
+        if tuple(img.shape[1:]) != (g.image_size, g.image_size, 3):
+            return None                        # example frames of another size go through preprocess_images first
+        img = img[: self.max_batch].contiguous()
+        audit = self._ctx.encode_audit(img.data_ptr(), img.shape[0], self._stream())      # {site: (max |x|, non-finite count)}
+        sites = {k: v[0] for k, v in audit.items()}
+        bad = {k: v[1] for k, v in audit.items() if v[1]}
+        limit = self.FP16_OPERAND_LIMIT if self.enc_dtype == "f16" else 3.0e38
+        if bad or max(sites.values()) > limit:
+            raise ValueError(f"encoder activations leave the {self.enc_dtype} operand range on the example batch: largest "
+                             f"|operand| per site {sites}, non-finite values {bad}; load with enc_dtype='bf16' "
+                             "(8 exponent bits) instead")
+        self.operand_range = sites
+        return sites
 
     def save_pretrained(self, step: int, checkpoint_path: str):
         os.makedirs(checkpoint_path, exist_ok=True)

@@ -124,3 +124,60 @@ def test_batched_evaluator_equals_one_episode_at_a_time():
             frame, _, done, trunc, _ = env.step(act)
         np.testing.assert_array_equal(np.array(env.log), logs[s])
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_batched_evaluator_against_the_oracle():
+    """N4 checked against the ORACLE, not against the HIP path itself: what every simulator is told to do by
+    `BatchEvaluator.run` equals the float64 restatement of the reference's per-episode loop -- DINOv2 hidden state of the
+    first frame -> create_tasks -> per step sample_actions -> un-normalise / ensemble / axis-angle / gripper rule
+    (data/simpler/evaluate.py:226-330, data/utils/hypervla_interface.py:141-304) -- run on the same frames.  The toy
+    simulator's frames depend on (seed, t) only, so the oracle can replay an episode without the actions."""
+    from hypervla import synthetic as syn
+    from hypervla.config import FULL, encoder_leaves, generated_leaves
+    from hypervla.evaluate import BatchEvaluator, DummyVectorEnv
+    from hypervla.model import HyperVLA
+    from oracle import hvla_ref_np as onp
+    g, E, setup = FULL, 3, "widowx_bridge"
+    m = HyperVLA.from_synthetic(g, max_batch=4)
+    base = syn.synthetic_instructions(E, g)["language_instruction"]
+
+    def tokenize(instrs):
+        idx = [int(s.split()[-1]) for s in instrs]
+        return {k: np.asarray(v)[idx] for k, v in base.items()}
+
+    goals = [2, 3, 2]
+    fns = [_fn(s, size=g.image_size, goal=goals[s], limit=4) for s in range(E)]      # model-sized frames: no resize in the loop
+    venv = DummyVectorEnv(fns, (g.image_size, g.image_size, 3))
+    try:
+        ev = BatchEvaluator(m, policy_setup=setup, pred_action_horizon=g.horizon, action_ensemble=True, crop=False)
+        res = ev.run(venv, tokenize, max_steps=6)
+        logs = venv.call("get_log")
+    finally:
+        venv.close()
+    assert res["steps"].tolist() == goals
+    P, leaves, enc = m.params, generated_leaves(g), dict(encoder_leaves(g))
+    stats = m.dataset_statistics["bridge_dataset"]["action"]
+    for s in range(E):
+        env = ToyEnv(s, size=g.image_size, goal=goals[s], limit=4)
+        frames = []
+        f, _ = env.reset()
+        for t in range(goals[s]):
+            frames.append(f)
+            f = env.step(np.zeros(7))[0]
+        frames = np.stack(frames)
+        hidden = onp.dinov2(P, g, enc, onp.normalize_images(frames[:1]))
+        ins = {"language_instruction": {k: np.asarray(v)[s:s + 1] for k, v in base.items()}}
+        bp, _ = onp.create_tasks(P, g, leaves, ins, {"patch_embeddings": hidden})
+        raws, logits = [], []
+        for t in range(goals[s]):
+            a, lg, _, _ = onp.sample_actions(P, g, enc, bp, frames[t:t + 1])
+            raws.append(a[0]), logits.append(lg[0])
+        _, want = onp.postprocess_episode(np.stack(raws), stats, setup, True, g.horizon)
+        got = np.asarray(logs[s])
+        assert got.shape == want.shape == (goals[s], 7)
+        # translation: |d action| <= 1e-3 times the un-normalisation scale (std <= 0.5); rotation goes through euler -> axis-angle
+        assert np.abs(got[:, :6] - want[:, :6]).max() <= 2e-3, np.abs(got[:, :6] - want[:, :6]).max()
+        if np.abs(np.stack(logits)).min() > 1e-2:              # thresholded column: equal wherever no logit sits on the threshold
+            np.testing.assert_array_equal(got[:, 6], want[:, 6])

@@ -324,6 +324,13 @@ def test_hf_torch_dinov2_state_dict_through_the_encoder(tmp_path):
     m0.save_pretrained(7, str(tmp_path))
     m = HyperVLA.load_pretrained(str(tmp_path), step=7, max_batch=4)
     assert m.example_batch["task"]["language_instruction"]["token_embedding"].shape == (1, 32, 768)   # model.py:190-192
+    # load_pretrained audited the 16-bit operand range on the example batch's frame (fp16 tops out at 65504)
+    assert set(m.operand_range) == {"layernorm_out", "qkv", "attention_out", "gelu_out"} and 0 < max(m.operand_range.values()) < 32768
+    huge = dict(m.params)                                          # a checkpoint whose fc1 output overflows fp16 is refused at load
+    k1 = "encoder_image_encoder_encoder_layer_0_mlp_fc1_bias"
+    huge[k1] = np.full_like(np.asarray(huge[k1]), 1.0e5)
+    with pytest.raises(ValueError, match="operand range"):
+        HyperVLA.from_synthetic(g, params=huge, max_batch=4).audit_operand_range(np.zeros((1, 224, 224, 3), np.uint8))
     im = syn.synthetic_images_structured(3, g)
     hid = m.encode_initial_image(im).cpu().numpy().astype(np.float64)
     ref = onp.dinov2(m.params, g, dict(encoder_leaves(g)), onp.normalize_images(im[:, 0]))
