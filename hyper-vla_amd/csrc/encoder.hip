@@ -113,6 +113,11 @@ struct GemmArgs {
 // pieces (measured on the QKV shape: the per-lane-column layout spent 8.6 us of a 24 us tile in its epilogue even on an
 // otherwise idle chip; the memory pipe handles one line per cycle, not one instruction).
 __device__ __forceinline__ int wperm(int rho) { return (rho & ~63) + 4 * (rho & 15) + ((rho >> 4) & 3); }
+// one entry of the per-image bias row: bias + (mean row . dW) / 4096 (dW is stored x 4096).  ONE definition, an explicit fma,
+// for the stand-alone table (EPI_CORR) and for the form fused into gemm64c_kernel: the same bits from either.
+__device__ __forceinline__ f32x4 corr_value(f32x4 acc, float b) {
+  return f32x4{fmaf(acc[0], 1.f / 4096.f, b), fmaf(acc[1], 1.f / 4096.f, b), fmaf(acc[2], 1.f / 4096.f, b), fmaf(acc[3], 1.f / 4096.f, b)};
+}
 
 // ROWBIAS: the bias row depends on the row's image (rows of several images in one tile: gemm64_kernel / gemm_kernel with a
 // corr table); otherwise one bias row per call (pre_b4, or g.bias).  FULL: every row of the wave tile exists -- straight-
@@ -124,7 +129,9 @@ __device__ __forceinline__ int wperm(int rho) { return (rho & ~63) + 4 * (rho & 
 template <typename Op, int EPI, int MT, bool FULL, bool ROWBIAS, bool CS = false>
 __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
                                                         int fr, int fq, const f32x4* pre_b4, const f32x4* pre_l4,
-                                                        typename Op::x4* cs = nullptr) {
+                                                        typename Op::x4* cs = nullptr,
+                                                        const __attribute__((address_space(3))) float* lds_corr = nullptr,   // ROWBIAS: [image - lds_img0][64] for this block's columns
+                                                        int lds_img0 = 0) {
   using T = typename Op::elem;
   const int n = n_base + 4 * fr;
   f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -157,8 +164,15 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
         if constexpr (ROWBIAS) {
           brow[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
           const int img = grow / g.S;
-          const float* bsrc = grow - img * g.S ? g.corr + (uint32_t)img * (uint32_t)g.N : g.bias;   // CLS row: plain bias
-          if (ok[u][r]) brow[u][r] = *reinterpret_cast<const f32x4*>(bsrc + (uint32_t)n);
+          if (lds_corr) {                                  // wave-uniform: the table was computed by this workgroup (gemm64c_kernel)
+            if (ok[u][r]) {
+              if (grow - img * g.S) brow[u][r] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds_corr + (img - lds_img0) * 64 + 4 * fr);
+              else brow[u][r] = *reinterpret_cast<const f32x4*>(g.bias + (uint32_t)n);      // CLS row: plain bias
+            }
+          } else {
+            const float* bsrc = grow - img * g.S ? g.corr + (uint32_t)img * (uint32_t)g.N : g.bias;   // CLS row: plain bias
+            if (ok[u][r]) brow[u][r] = *reinterpret_cast<const f32x4*>(bsrc + (uint32_t)n);
+          }
         }
       }
 #pragma unroll
@@ -167,7 +181,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if constexpr (EPI == EPI_PATCH) t[c] = acc[c][mp + u] * q + b4[c];      // patch weights are stored x256 (16-bit range)
-        else if constexpr (EPI == EPI_CORR) t[c] = acc[c][mp + u] * (1.f / 4096.f) + b4[c];   // dW is stored x4096
+        else if constexpr (EPI == EPI_CORR) t[c] = corr_value(acc[c][mp + u], b4[c]);
         else if constexpr (ROWBIAS) t[c] = acc[c][mp + u] + f32x4{brow[u][0][c], brow[u][1][c], brow[u][2][c], brow[u][3][c]};
         else t[c] = acc[c][mp + u] + b4[c];
         if constexpr (EPI == EPI_QKV) t[c] *= q;
@@ -408,6 +422,116 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
     c.A = g.abar2; c.W = g.dW2; c.out = g.corr2; c.M = g.M2; c.row0 = 0; c.row_step = 1; c.corr = nullptr;
     gemm64_body<Op, EPI_CORR>(c, blockIdx.x - g.nb1);
   }
+}
+
+// gemm64c_kernel -- gemm64_kernel for a SMALL batch (all rows, up to 2047) with the per-image bias rows computed inside:
+// the workgroup's 64 rows belong to at most 16 images (two at S = 257); their mean rows against the block's 64 columns of
+// dW are one more 16-row MFMA tile over the same K loop (wave w takes n-tile w: two MFMAs per K-tile and wave), staged
+// beside A and W (dW 8 KB, mean rows 4 KB per stage).  The accumulators go through corr_value() into a 16 x 64 table in LDS
+// that the epilogue reads instead of a table in memory: the separate table launch in front of every GEMM (48 per step,
+// 12 us each at B = 1) is gone.  Same operands, same MFMA, same k order as gemm64_body<EPI_CORR> => the same bias rows.
+constexpr int SNSC = 5, SSTC = 28672;   // stages x (A 8 KB | W 8 KB | dW 8 KB | mean rows 4 KB)
+template <typename Op, int EPI>
+__global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
+  using T = typename Op::elem;
+  using X8 = typename Op::x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbm = (g.M + SBM - 1) / SBM;
+  const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
+  const int m0 = bm * SBM, n0 = bn * SBN;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const T* dW = reinterpret_cast<const T*>(g.dW2);
+  const T* AB = reinterpret_cast<const T*>(g.abar2);
+  const int img0 = (g.row0 + m0 * g.row_step) / g.S;          // first image of this block's rows
+  const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
+  uint32_t aoff[2], woff[2], boff;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rl = 32 * j + 8 * wave + (lane >> 3);
+    int m = m0 + rl;
+    m = m < g.M ? m : g.M - 1;
+    aoff[j] = (uint32_t)(g.row0 + m * g.row_step) * (uint32_t)g.K + sch;
+    woff[j] = (uint32_t)(n0 + wperm(rl)) * (uint32_t)g.K + sch;
+  }
+  {
+    int img = img0 + 8 * wave + (lane >> 3);                  // rows 0..31 of the mean-row tile; the MFMA reads rows 0..15
+    img = img < g.M2 ? img : g.M2 - 1;
+    boff = (uint32_t)img * (uint32_t)g.K + sch;
+  }
+  const int KT = g.K / 64;
+  auto issue = [&](int kt) {
+    char* base = smem + (kt % SNSC) * SSTC + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoff[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + j * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + woff[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + 8192 + j * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dW + woff[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(base + 16384 + j * 4096), 16, 0, 0);
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(AB + boff + kt * 64),
+                                     (__attribute__((address_space(3))) void*)(base + 24576), 16, 0, 0);
+  };
+  f32x4 acc[4][1], acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw0 = (fq ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
+  const int a_off = (wave * 16 + fr) * 128, w_off = 8192 + fr * 128;
+  const int d_off = 16384 + (wave * 16 + fr) * 128, b_off = 24576 + fr * 128;
+#pragma unroll
+  for (int s = 0; s < SNSC - 1; ++s)
+    if (s < KT) issue(s);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int issued = kt + SNSC - 1 < KT ? kt + SNSC - 1 : KT;
+    switch (issued - kt - 1) {                       // K-tiles issued after tile kt may stay in flight (7 pieces each)
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + SNSC - 1 < KT) issue(kt + SNSC - 1);
+    const char* lb = smem + (kt % SNSC) * SSTC;
+    X8 fa[2], fw[4][2], fb[2], fd[2];
+    fa[0] = *reinterpret_cast<const X8*>(lb + a_off + sw0);
+    fa[1] = *reinterpret_cast<const X8*>(lb + a_off + sw1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      fw[nt][0] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw0);
+      fw[nt][1] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw1);
+    }
+    fb[0] = *reinterpret_cast<const X8*>(lb + b_off + sw0);
+    fb[1] = *reinterpret_cast<const X8*>(lb + b_off + sw1);
+    fd[0] = *reinterpret_cast<const X8*>(lb + d_off + sw0);
+    fd[1] = *reinterpret_cast<const X8*>(lb + d_off + sw1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][0] = Op::mma16(fa[kk], fw[nt][kk], acc[nt][0]);
+      acc2 = Op::mma16(fb[kk], fd[kk], acc2);
+    }
+  }
+  // acc2[r] = (mean row of image img0 + 4 fq + r) . dW[:, n0 + 4 fr + wave] x 4096  ->  table[image - img0][4 fr + wave]
+  __builtin_amdgcn_s_barrier();                      // every wave is done with the last stage: its space takes the table
+  float* table = reinterpret_cast<float*>(smem);
+  {
+    const f32x4 cv = corr_value(acc2, g.bias[n0 + 4 * fr + wave]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) table[(4 * fq + r) * 64 + 4 * fr + wave] = cv[r];
+  }
+  __syncthreads();
+  const auto lt = reinterpret_cast<const __attribute__((address_space(3))) float*>((__attribute__((address_space(3))) char*)smem);
+  if (m0 + wave * 16 + 16 <= g.M) gemm_epilogue_rows_impl<Op, EPI, 1, true, true>(acc, g, m0 + wave * 16, n0, fr, fq, nullptr, nullptr, nullptr, lt, img0);
+  else gemm_epilogue_rows_impl<Op, EPI, 1, false, true>(acc, g, m0 + wave * 16, n0, fr, fq, nullptr, nullptr, nullptr, lt, img0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -776,6 +900,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // out of the same launch (no partial sums in memory, no second kernel), and the order of the additions depends on nothing
 // but the image.  A batch of 256 images is exactly one workgroup per CU.  E % 4 == 0, E <= 1024.
 constexpr int LNW = 16;
+// one row: statistics (f32, two passes over the registers), the f32 outputs y (what the column sums add) and the 16-bit store.
+// Shared by the one-workgroup-per-image kernel and the split form below, so that a row and its contribution to the mean row
+// are the same bits in both.
+template <typename Op>
+__device__ __forceinline__ void ln_row(const f32x4 (&cur)[4], const f32x4 (&s4)[4], const f32x4 (&b4)[4], int n4, int E, int lane,
+                                       typename Op::elem* __restrict__ orow, f32x4 (&y)[4]) {
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
+  sum = wave64_sum(sum);
+  const float mean = sum / E;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (lane + 64 * i < n4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = cur[i][j] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  sq = wave64_sum(sq);
+  const float rstd = rsqrtf(sq / E + 1e-6f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int col = lane + 64 * i;
+    y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (col < n4) {
+      typename Op::x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[i][j] = (cur[i][j] - mean) * rstd * s4[i][j] + b4[i][j];
+        o[j] = (typename Op::elem)y[i][j];
+      }
+      reinterpret_cast<typename Op::x4*>(orow)[col] = o;
+    }
+  }
+}
+
 template <typename Op>
 __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
@@ -804,42 +968,10 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __
   load(cur, wave);
   for (int row = wave; row < S; row += LNW) {                        // wave-uniform
     load(nxt, row + LNW);
-    float sum = 0.f;
+    f32x4 y[4];
+    ln_row<Op>(cur, s4, b4, n4, E, lane, out + ((size_t)b * S + row) * E, y);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
-    sum = wave64_sum(sum);
-    const float mean = sum / E;
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (lane + 64 * i < n4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = cur[i][j] - mean;
-          sq += d * d;
-        }
-      }
-    }
-    sq = wave64_sum(sq);
-    const float rstd = rsqrtf(sq / E + 1e-6f);
-    typename Op::elem* orow = out + ((size_t)b * S + row) * E;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = lane + 64 * i;
-      if (col < n4) {
-        f32x4 y;
-        typename Op::x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          y[j] = (cur[i][j] - mean) * rstd * s4[i][j] + b4[i][j];
-          o[j] = (typename Op::elem)y[j];
-        }
-        cs[i] += y;
-        reinterpret_cast<typename Op::x4*>(orow)[col] = o;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+    for (int i = 0; i < 4; ++i) cs[i] += y[i], cur[i] = nxt[i];
   }
   if (!abar) return;
 #pragma unroll
@@ -858,10 +990,78 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __
   }
 }
 
+// The same LayerNorm for SMALL batches, where one workgroup per image leaves the chip empty and a launch lasts as long as one
+// CU needs for 257 rows (26 us at B = 1, 25 launches per step): LNW workgroups per image, workgroup j takes the rows of
+// "wave j" of the kernel above (j, j + 16, ...), one row per wave, and adds their y in that same order (through LDS) into
+// partial[b][j][E]; layernorm_mean_kernel then combines the LNW partials in wave order.  Same additions in the same order =>
+// the same mean row, bit for bit, whichever form ran (the batch-invariance tests cross them).
+template <typename Op>
+__global__ __launch_bounds__(LNW * 64) void layernorm_split_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
+                                                                   const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                   float* __restrict__ partial, int S, int E) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* ys = reinterpret_cast<f32x4*>(smem);                        // [rows of this workgroup][E / 4]
+  const int j = blockIdx.x, b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n4 = E / 4;
+  const int nrows = (S - j + LNW - 1) / LNW;                         // rows j, j + LNW, ...: 16 or 17 at S = 257
+  f32x4 s4[4], b4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int col = lane + 64 * i;
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    s4[i] = col < n4 ? reinterpret_cast<const f32x4*>(scale)[col] : z;
+    b4[i] = col < n4 ? reinterpret_cast<const f32x4*>(bias)[col] : z;
+  }
+  for (int v = wave; v < nrows; v += LNW) {                          // wave-uniform; one row per wave, a second one for row 256
+    const int row = j + LNW * v;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((size_t)b * S + row) * E);
+    f32x4 cur[4], y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = lane + 64 * i;
+      cur[i] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    ln_row<Op>(cur, s4, b4, n4, E, lane, out + ((size_t)b * S + row) * E, y);
+    if (partial) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < n4) ys[v * n4 + lane + 64 * i] = y[i];
+    }
+  }
+  if (!partial) return;
+  __syncthreads();
+  if ((int)threadIdx.x < n4) {
+    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < nrows; ++v) cs += ys[v * n4 + threadIdx.x];
+    reinterpret_cast<f32x4*>(partial + ((size_t)b * LNW + j) * E)[threadIdx.x] = cs;
+  }
+}
+template <typename Op>
+__global__ __launch_bounds__(256) void layernorm_mean_kernel(const float* __restrict__ partial, typename Op::elem* __restrict__ abar,
+                                                             int S, int E) {
+  const int b = blockIdx.x, n4 = E / 4;
+  if ((int)threadIdx.x >= n4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(partial + (size_t)b * LNW * E);
+  f32x4 t = p[threadIdx.x];
+#pragma unroll
+  for (int w = 1; w < LNW; ++w) t += p[w * n4 + threadIdx.x];
+  const float inv = 1.f / (float)S;
+  typename Op::x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (typename Op::elem)(t[j] * inv);
+  reinterpret_cast<typename Op::x4*>(abar + (size_t)b * E)[threadIdx.x] = o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Attention, head_dim 64.  qkv [B*S][3E] 16-bit (q already scaled by log2(e)/sqrt(64)); out o [B*S][E].
 constexpr int AKLD = 72;          // K row stride in LDS (halves): 144 B
 constexpr int AVLD = 64;          // V row stride (halves): 128 B, 64-B halves swapped on rows with bit 1 set
+// K rows are 128 B = half of the 64 banks, so a row's bank half is its row parity, and the 16-B chunk swizzle (chunk ^ key & 7)
+// alone leaves every ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: guide, LDS table) with two keys
+// per 4-bank slot (SQ_LDS_BANK_CONFLICT was 27 % of the LDS cycles of this kernel).  Storing key k in row kperm(k) -- bits 0
+// and 3 exchanged -- makes the bank half bit 3 of the key, which differs inside every such pair: conflict-free.
+__device__ __forceinline__ constexpr int kperm(int k) { return (k & ~9) | ((k & 1) << 3) | ((k >> 3) & 1); }
 
 // transposed LDS read (ds_read_b64_tr_b16, guide T10): per 16-lane group a 4-row x 16-column block of 16-bit
 // elements comes back column-major; lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane i
@@ -945,7 +1145,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   for (int it = 0; it < STG; ++it) {
     if (it * nthr >= SP * 8) break;
     const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
-    if (i < SP * 8) *reinterpret_cast<X8*>(Ks + key * AVLD + ((ch ^ (key & 7)) * 8)) = kreg[it];
+    if (i < SP * 8) *reinterpret_cast<X8*>(Ks + kperm(key) * AVLD + ((ch ^ (key & 7)) * 8)) = kreg[it];
   }
   __syncthreads();
   HVLA_ASTAMP();                                           // 1 K staged
@@ -965,13 +1165,14 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   const int vsw = ((i16 >> 3) & 1) << 5;
   const T* vtr = Vs + ((g16 >> 1) * 4 + (i16 >> 2)) * AVLD + (g16 & 1) * 16 + (i16 & 3) * 4;
   const int kswz = col & 7;                                // K chunk swizzle of this lane's key row
+  const int colp = kperm(col);                             // its row inside a 32-key tile
   // Two passes over the resident K tiles instead of an online softmax: the matrix pipe is idle most of the
   // time here (head_dim 64: 8 MFMAs per 1024 scores), so recomputing K.Q^T (4 MFMAs) is cheaper than the
   // per-tile rescale of O and the running-max bookkeeping.
   //   pass 1: row max (scores are in the log2 domain: q carries 1/sqrt(64) * log2 e from the QKV epilogue)
   //   pass 2: accumulator initialised to -max, so p = exp2(acc) with no subtract; invalid keys get -1e30
   auto kfrag = [&](int kt, int ks) {
-    return *reinterpret_cast<const X8*>(Ks + (kt * 32 + col) * AVLD + (((2 * ks + half) ^ kswz) * 8));
+    return *reinterpret_cast<const X8*>(Ks + (kt * 32 + colp) * AVLD + (((2 * ks + half) ^ kswz) * 8));
   };
   // This kernel is VALU-issue-bound (it spent about 4 VALU cycles per MFMA cycle): the accumulator input of a score tile
   // is the inline constant 0 and the padding mask only exists in the peeled last key tile, so the loops carry no
@@ -1062,7 +1263,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     for (int c = 0; c < 4; ++c) qx[c] = *reinterpret_cast<const X8*>(qxs + half * 32 + c * 8);
     auto score = [&](int key) {          // sum over this half's 32 d
       float a = 0.f;
-      const T* kr = Ks + key * AVLD;
+      const T* kr = Ks + kperm(key) * AVLD;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const X8 kv = *reinterpret_cast<const X8*>(kr + (((half * 4 + c) ^ (key & 7)) * 8));
@@ -1219,6 +1420,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm256p_kernel<Op, EPI_GELU, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true>))
     SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
     SETA((gemm64_kernel<Op, EPI_RES>)) SETA((gemm64_kernel<Op, EPI_CORR>))
+    SETA((gemm64c_kernel<Op, EPI_QKV>)) SETA((gemm64c_kernel<Op, EPI_GELU>)) SETA((gemm64c_kernel<Op, EPI_RES>))
 #undef SETA
     di.attr[opi] = true;
   }
@@ -1261,6 +1463,16 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       pf.end(cat, st);
       return true;
     }
+    if constexpr (EPI != EPI_PATCH) {
+      if (comp && M <= G64_MAXM && fits32 && N % SBN == 0 && K % 64 == 0 && S >= 5) {     // small batch: the bias rows are computed inside the GEMM
+        a.abar2 = ws.abar; a.dW2 = dW; a.M2 = B;
+        pf.end(CAT_COMP, st);
+        pf.begin(cat, st);
+        hipLaunchKernelGGL((gemm64c_kernel<Op, EPI>), dim3(((M + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNSC * SSTC, st, a);
+        pf.end(cat, st);
+        return false;
+      }
+    }
     if (comp) {                                        // the same gemm64_body<EPI_CORR> arithmetic as the fused launch above
       GemmArgs c{ws.abar, dW, B, N, K, bias, nullptr, ws.corr, P, S, 0, 1.f};
       hipLaunchKernelGGL((gemm64_kernel<Op, EPI_CORR>), dim3(((B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
@@ -1275,7 +1487,15 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     pf.end(cat, st);
     return false;
   };
+  constexpr int LN_SPLIT_MAXB = 64;    // up to here a LayerNorm is LNW workgroups per image + a finalising launch (same bits)
   auto layernorm = [&](const float* sc, const float* bi) {           // norm1 / norm2 (+ the column sums of the output)
+    if (B <= LN_SPLIT_MAXB && E <= 1024 && (size_t)LNW * E * sizeof(float) <= (size_t)S * F * sizeof(T)) {
+      float* partial = comp ? reinterpret_cast<float*>(ws.g) : nullptr;      // ws.g is free at both LayerNorms: [B][LNW][E] f32
+      hipLaunchKernelGGL((layernorm_split_kernel<Op>), dim3(LNW, B), dim3(LNW * 64), (size_t)((S + LNW - 1) / LNW) * E * sizeof(float),
+                         st, ws.x, reinterpret_cast<T*>(ws.h), sc, bi, partial, S, E);
+      if (comp) hipLaunchKernelGGL((layernorm_mean_kernel<Op>), dim3(B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), S, E);
+      return;
+    }
     hipLaunchKernelGGL((layernorm_img_kernel<Op>), dim3(B), dim3(LNW * 64), (size_t)LNW * E * sizeof(float), st, ws.x,
                        reinterpret_cast<T*>(ws.h), sc, bi, comp ? reinterpret_cast<T*>(ws.abar) : nullptr, S, E);
   };
