@@ -130,8 +130,8 @@ template <typename Op, int EPI, int MT, bool FULL, bool ROWBIAS, bool CS = false
 __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
                                                         int fr, int fq, const f32x4* pre_b4, const f32x4* pre_l4,
                                                         typename Op::x4* cs = nullptr,
-                                                        const __attribute__((address_space(3))) float* lds_corr = nullptr,   // ROWBIAS: [image - lds_img0][64] for this block's columns
-                                                        int lds_img0 = 0) {
+                                                        const __attribute__((address_space(3))) float* lds_corr = nullptr,   // ROWBIAS, lds_img0 >= 0: [image - lds_img0][64] for this
+                                                        int lds_img0 = -1) {                                                 // block's columns (LDS offset 0 is a valid address)
   using T = typename Op::elem;
   const int n = n_base + 4 * fr;
   f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -164,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
         if constexpr (ROWBIAS) {
           brow[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
           const int img = grow / g.S;
-          if (lds_corr) {                                  // wave-uniform: the table was computed by this workgroup (gemm64c_kernel)
+          if (lds_img0 >= 0) {                             // wave-uniform: the table was computed by this workgroup (gemm64c_kernel)
             if (ok[u][r]) {
               if (grow - img * g.S) brow[u][r] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds_corr + (img - lds_img0) * 64 + 4 * fr);
               else brow[u][r] = *reinterpret_cast<const f32x4*>(g.bias + (uint32_t)n);      // CLS row: plain bias
@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 // W-row permutation, MFMA and k order are those of gemm256p_kernel, so a row gets the same bits whichever kernel
 // computes it.
 constexpr int SBM = 64, SBN = 64, SNS = 6;
-template <typename Op, int EPI>
+// NS stages of 16 KB: 6 (5 K-tiles in flight, one workgroup per CU) or 4 (64 KB: two workgroups per CU, for the launches
+// with more blocks than CUs -- the QKV and fc1 shapes -- which otherwise run as two rounds).  Same bits either way.
+template <typename Op, int EPI, int NS = SNS>
 __device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
   using T = typename Op::elem;
   using X8 = typename Op::x8;
@@ -360,7 +362,7 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
   }
   const int KT = g.K / 64;
   auto issue = [&](int kt) {
-    char* base = smem + (kt % SNS) * 16384 + wave * 1024;
+    char* base = smem + (kt % NS) * 16384 + wave * 1024;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoff[j] + kt * 64),
@@ -376,10 +378,10 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
   const int sw0 = (fq ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
   const int a_off = (wave * 16 + fr) * 128, w_off = 8192 + fr * 128;
 #pragma unroll
-  for (int s = 0; s < SNS - 1; ++s)
+  for (int s = 0; s < NS - 1; ++s)
     if (s < KT) issue(s);
   for (int kt = 0; kt < KT; ++kt) {
-    const int issued = kt + SNS - 1 < KT ? kt + SNS - 1 : KT;
+    const int issued = kt + NS - 1 < KT ? kt + NS - 1 : KT;
     switch (issued - kt - 1) {                       // K-tiles issued after tile kt may stay in flight (4 pieces each)
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -390,8 +392,7 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();                    // tile kt landed for every wave; everyone is done reading tile kt - 1
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + SNS - 1 < KT) issue(kt + SNS - 1);      // into the stage of tile kt - 1
-    const char* lb = smem + (kt % SNS) * 16384;
+    const char* lb = smem + (kt % NS) * 16384;
     X8 fa[2], fw[4][2];
     fa[0] = *reinterpret_cast<const X8*>(lb + a_off + sw0);
     fa[1] = *reinterpret_cast<const X8*>(lb + a_off + sw1);
@@ -400,6 +401,8 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
       fw[nt][0] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw0);
       fw[nt][1] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw1);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NS - 1 < KT) issue(kt + NS - 1);      // into the stage of tile kt - 1; issued while the fragment reads are in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -413,14 +416,14 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
 // Blocks [0, nb1): the GEMM itself.  Blocks [nb1, ...): a second, independent problem of the same N and K in the same
 // launch -- the per-image bias rows of the big GEMM that follows (corr2 = bias + abar2 . dW2 / 4096, one row per image),
 // so that the B CLS rows and the B mean rows, both pure latency, cost one launch instead of two.
-template <typename Op, int EPI>
+template <typename Op, int EPI, int NS = SNS>
 __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
   if (g.nb1 == 0 || (int)blockIdx.x < g.nb1) {
-    gemm64_body<Op, EPI>(g, blockIdx.x);
+    gemm64_body<Op, EPI, NS>(g, blockIdx.x);
   } else {
     GemmArgs c = g;
     c.A = g.abar2; c.W = g.dW2; c.out = g.corr2; c.M = g.M2; c.row0 = 0; c.row_step = 1; c.corr = nullptr;
-    gemm64_body<Op, EPI_CORR>(c, blockIdx.x - g.nb1);
+    gemm64_body<Op, EPI_CORR, NS>(c, blockIdx.x - g.nb1);
   }
 }
 
@@ -497,7 +500,6 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + SNSC - 1 < KT) issue(kt + SNSC - 1);
     const char* lb = smem + (kt % SNSC) * SSTC;
     X8 fa[2], fw[4][2], fb[2], fd[2];
     fa[0] = *reinterpret_cast<const X8*>(lb + a_off + sw0);
@@ -511,6 +513,8 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     fb[1] = *reinterpret_cast<const X8*>(lb + b_off + sw1);
     fd[0] = *reinterpret_cast<const X8*>(lb + d_off + sw0);
     fd[1] = *reinterpret_cast<const X8*>(lb + d_off + sw1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + SNSC - 1 < KT) issue(kt + SNSC - 1);    // into the stage of tile kt - 1; issued while the fragment reads are in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1420,6 +1424,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm256p_kernel<Op, EPI_GELU, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true>))
     SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
     SETA((gemm64_kernel<Op, EPI_RES>)) SETA((gemm64_kernel<Op, EPI_CORR>))
+    SETA((gemm64_kernel<Op, EPI_QKV, 4>)) SETA((gemm64_kernel<Op, EPI_GELU, 4>)) SETA((gemm64_kernel<Op, EPI_RES, 4>))
     SETA((gemm64c_kernel<Op, EPI_QKV>)) SETA((gemm64c_kernel<Op, EPI_GELU>)) SETA((gemm64c_kernel<Op, EPI_RES>))
 #undef SETA
     di.attr[opi] = true;
@@ -1451,7 +1456,12 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       c.nb1 = ((B + SBM - 1) / SBM) * (N / SBN);
       int nblocks = c.nb1;
       if (comp) { c.abar2 = ws.abar; c.dW2 = dW; c.corr2 = ws.corr; c.M2 = B; nblocks *= 2; }
-      hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
+      if constexpr (EPI != EPI_PATCH) {
+        if (nblocks > ncu) hipLaunchKernelGGL((gemm64_kernel<Op, EPI, 4>), dim3(nblocks), dim3(256), 4 * 16384, st, c);   // two workgroups per CU: one round
+        else hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
+      } else {
+        hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
+      }
       pf.end(CAT_COMP, st);
       const int nbn = N / HBN_;
       a.corr = comp ? ws.corr : nullptr;

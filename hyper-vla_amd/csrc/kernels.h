@@ -113,6 +113,7 @@ struct PolicyParams {
   float* logits;             // [B, horizon] or null
   int B, E, P, L, M, horizon, action_dim;
   float tanh_scale, max_action;
+  float* amap = nullptr;     // [B, L, heads, P] or null: attention of the action token over the patch keys, every layer
 #ifdef HVLA_BENCH_HOOKS
   unsigned long long* stamps = nullptr;   // libhvla_bench.so: shader-clock time stamps of episode 0 / wave 0 at the phase boundaries
 #endif
