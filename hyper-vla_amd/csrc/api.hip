@@ -61,6 +61,7 @@ struct hvla_ctx {
   // workspaces (sized for cfg.max_batch)
   DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_corr, ws_abar, tokens, flags;
   Profiler prof;
+  float *amap_dino = nullptr, *amap_head = nullptr;     // hvla_set_attention_outputs: caller-owned device buffers (opt-in)
   // cfg.streams == 2: helper stream and fork / join events of hvla_step
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -475,6 +476,7 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
                   static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + (size_t)b0 * gper * 2,
                   ctx->ws_corr.as<float>() + (size_t)b0 * (F > 3 * E ? F : 3 * E),
                   static_cast<char*>(ctx->ws_abar.p) + (size_t)b0 * (F > E ? F : E) * 2};
+  if (ctx->amap_dino) ws.amap = ctx->amap_dino + (size_t)b0 * g.enc_layers * g.enc_heads * g.P();
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
                              &ctx->prof, keep_cls));
@@ -530,6 +532,7 @@ static int policy_range(hvla_ctx* ctx, const hvla_weights* w, const float* token
                  w->vf.as<float>() + (size_t)b0 * pl.Gv, tokens + (size_t)b0 * g.P() * g.E,
                  actions + (size_t)b0 * g.horizon * g.action_dim, logits ? logits + (size_t)b0 * g.horizon : nullptr,
                  nb, g.E, g.P(), g.L, g.M, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
+  if (ctx->amap_head) p.amap = ctx->amap_head + (size_t)b0 * g.L * g.H * g.P();
   ctx->prof.begin(HVLA_PROF_POLICY, st);
   HIPCHK(ctx, launch_policy(p, st));
   ctx->prof.end(HVLA_PROF_POLICY, st);
@@ -544,6 +547,13 @@ int hvla_policy(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float
   if (!tokens || !actions) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return policy_range(ctx, w, tokens, actions, logits, 0, B, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hvla_set_attention_outputs(hvla_ctx* ctx, float* dino_cls_attention, float* head_attention) {
+  if (!ctx) return HVLA_E_STATE;
+  ctx->amap_dino = dino_cls_attention;
+  ctx->amap_head = head_attention;
+  return HVLA_OK;
 }
 
 int hvla_step(hvla_ctx* ctx, const hvla_weights* w, const uint8_t* images, float* actions, float* logits, int32_t B,

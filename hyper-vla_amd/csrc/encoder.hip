@@ -1082,9 +1082,11 @@ __device__ __forceinline__ X8 tr_read2(const void* p0, const void* p1) {
 
 // omean (nullable): [B][E] 16-bit mean over all S tokens of the image of the output, the operand of the out-projection's
 // weight-rounding compensation (the corr rows of gemm64_kernel): the workgroup owns every row of its 64 columns.
-template <typename Op>
+template <typename Op, bool AMAP = false>      // AMAP: the opt-in instantiation that also exports the CLS query's attention row
 __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, typename Op::elem* __restrict__ o,
-                                 int S, int E, int H, typename Op::elem* __restrict__ omean
+                                 int S, int E, int H, typename Op::elem* __restrict__ omean,
+                                 float* __restrict__ amap     // nullable: this layer's slice [B][..][H][S - 1] of the CLS query's attention over the patch keys
+                                 , int amap_stride            // floats between two images in amap (= layers * H * (S - 1))
 #ifdef HVLA_BENCH_HOOKS
                                  , unsigned long long* stamps = nullptr      // libhvla_bench.so: shader-clock stamps of workgroup `stamp_wg`, wave 0
                                  , int stamp_wg = 0
@@ -1219,6 +1221,10 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       const f32x2v p2 = {__builtin_amdgcn_exp2f(sc[r] - mx), __builtin_amdgcn_exp2f(sc[r + 1] - mx)};
+      if (AMAP && wave == 0 && col == 0) {                 // query 0 = the CLS token: its unnormalised row waits in `part` (free until the tail)
+        part[kt * 32 + crow(r, half)] = p2[0];
+        part[kt * 32 + crow(r + 1, half)] = p2[1];
+      }
       lsum2 += p2;
       pf[r >> 3][r & 7] = (T)p2[0];
       pf[r >> 3][(r & 7) + 1] = (T)p2[1];
@@ -1238,6 +1244,11 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   const float lsum = lsum2[0] + lsum2[1];
   const float inv = 1.f / (lsum + __shfl_xor(lsum, 32, 64));
   HVLA_ASTAMP();                                           // 4 pass 2 done
+  if (AMAP && wave == 0) {       // outputs.attentions[layer][b, head, 0, 1:] (base_vit.py:117-118, hypervla_interface.py:210-211)
+    const float i0 = lane_bcast(inv, 0);
+    float* am = amap + (size_t)b * amap_stride + (size_t)head * (S - 1);
+    for (int j = lane; j < S - 1; j += 64) am[j] = part[1 + j] * i0;
+  }
   {
     T* op = o + ((size_t)b * S + q) * E + head * 64;
 #pragma unroll
@@ -1417,7 +1428,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
 #define SETA(K) \
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     SETA((gemm_kernel<Op, EPI_PATCH>)) SETA((gemm_kernel<Op, EPI_QKV>)) SETA((gemm_kernel<Op, EPI_GELU>))
-    SETA((gemm_kernel<Op, EPI_RES>)) SETA((attention_kernel<Op>))
+    SETA((gemm_kernel<Op, EPI_RES>)) SETA((attention_kernel<Op, false>)) SETA((attention_kernel<Op, true>))
     SETA((gemm256p_kernel<Op, EPI_PATCH, false>)) SETA((gemm256p_kernel<Op, EPI_QKV, false>))
     SETA((gemm256p_kernel<Op, EPI_GELU, false>)) SETA((gemm256p_kernel<Op, EPI_RES, false>))
     SETA((gemm256p_kernel<Op, EPI_PATCH, true>)) SETA((gemm256p_kernel<Op, EPI_QKV, true>))
@@ -1556,8 +1567,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     gemm(EQ{}, ws.h, L.wqkv, L.dqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, 2);                       // the LayerNorm wrote the mean row itself
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
     pf.begin(3, st);
-    hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
-                       reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr);
+    if (ws.amap)
+      hipLaunchKernelGGL((attention_kernel<Op, true>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
+                         reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr,
+                         ws.amap + (size_t)l * H * (S - 1), g.enc_layers * H * (S - 1));
+    else
+      hipLaunchKernelGGL((attention_kernel<Op, false>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
+                         reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr,
+                         nullptr, 0);
     pf.end(3, st);
     audit_of(ws.h, (size_t)M * E, 2);
     gemm(ER{}, ws.h, L.wo, L.dwo, E, E, L.bo, L.ls1, ws.x, 0, 4);                     // the attention kernel wrote the mean row itself
@@ -1636,9 +1653,9 @@ hipError_t debug_attention_stamps(const void* qkv, void* o, void* omean, int B, 
   const int KT = (S + 31) / 32;
   const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * 66 * sizeof(float) + 64 * sizeof(T) +
                            (size_t)(KT - 1) * 64 * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<Op>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(attention_kernel<Op>, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st, reinterpret_cast<const T*>(qkv),
-                     reinterpret_cast<T*>(o), S, E, H, reinterpret_cast<T*>(omean), stamps, wg);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<Op, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((attention_kernel<Op, false>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st, reinterpret_cast<const T*>(qkv),
+                     reinterpret_cast<T*>(o), S, E, H, reinterpret_cast<T*>(omean), nullptr, 0, stamps, wg);
   return hipGetLastError();
 }
 #endif  // HVLA_BENCH_HOOKS

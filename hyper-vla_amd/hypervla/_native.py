@@ -22,7 +22,7 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
            "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit", "hvla_train_accumulate", "hvla_train_bucket_ranges",
-           "hvla_train_wait_bucket"]
+           "hvla_train_wait_bucket", "hvla_set_attention_outputs"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy",
               "small_row_gemms"]      # mean rows + the 2 B latency-bound rows per GEMM: CLS rows and weight-rounding compensation rows
 
@@ -130,6 +130,8 @@ def load_library():
     lib.hvla_profile_read.restype = C.c_int
     lib.hvla_encode_audit.argtypes = [vp, vp, i32, C.POINTER(C.c_float), C.POINTER(i32), vp]
     lib.hvla_encode_audit.restype = C.c_int
+    lib.hvla_set_attention_outputs.argtypes = [vp, vp, vp]
+    lib.hvla_set_attention_outputs.restype = C.c_int
     lib.hvla_selftest.argtypes = [vp, vp]
     lib.hvla_selftest.restype = C.c_int
     _lib = lib
@@ -214,6 +216,11 @@ class Context:
         mx, bad = (C.c_float * 4)(), (C.c_int32 * 4)()
         self._check(self.lib.hvla_encode_audit(self.h, C.c_void_p(images_ptr), B, mx, bad, C.c_void_p(stream)), "hvla_encode_audit")
         return {k: (float(mx[i]), int(bad[i])) for i, k in enumerate(("layernorm_out", "qkv", "attention_out", "gelu_out"))}
+
+    def set_attention_outputs(self, dino_ptr: int = 0, head_ptr: int = 0):
+        """Device buffers the following encode / policy / step calls write the two attention maps into (0 = off)."""
+        self._check(self.lib.hvla_set_attention_outputs(self.h, C.c_void_p(dino_ptr or None), C.c_void_p(head_ptr or None)),
+                    "hvla_set_attention_outputs")
 
     def selftest(self, stream: int = 0):
         self._check(self.lib.hvla_selftest(self.h, C.c_void_p(stream)), "hvla_selftest")

@@ -84,8 +84,8 @@ class InferenceWrapper:
                  crop: bool = False, save_attention_map: bool = False, padded_resize: bool = False):
         if policy_setup not in _DATASET:
             raise ValueError(f"Unknown policy setup: {policy_setup}")
-        if save_attention_map:
-            raise NotImplementedError("attention maps are not materialised by the HIP path")
+        self.save_attention_map = save_attention_map          # hypervla_interface.py:74,208-217
+        self.dino_attention_map = self.head_attention_map = None
         self.model, self.policy_setup = model, policy_setup
         self.image_size, self.horizon = image_size, horizon
         self.pred_action_horizon, self.exec_horizon = pred_action_horizon, exec_horizon
@@ -191,9 +191,13 @@ class InferenceWrapper:
         pad_mask = np.ones(n, dtype=np.float64)
         pad_mask[: n - min(n, self.num_image_history)] = 0
         start = time.time()
-        raw_actions, _ = self.model.sample_actions(images, self.instruction_dict, self.task, pad_mask[None],
-                                                   self.base_params, rng=None, image_embeddings=image_embeddings)
+        extra = {"attention_maps": True} if self.save_attention_map else {}     # the reference's signature otherwise
+        raw_actions, inter = self.model.sample_actions(images, self.instruction_dict, self.task, pad_mask[None],
+                                                       self.base_params, rng=None, image_embeddings=image_embeddings, **extra)
         end = time.time()                      # numpy in -> numpy out: sample_actions has synchronised
+        if self.save_attention_map:            # hypervla_interface.py:208-217: [12, 12, P] and [4, 4, P] of this episode
+            self.dino_attention_map = np.asarray(inter["dino_cls_attention"])[0]
+            self.head_attention_map = np.asarray(inter["head_attention"])[0]
         raw_action, action = self.postprocess(np.asarray(raw_actions)[0])
         self.episode_step += 1
         return raw_action, action, image, (self.task_description, self.task), (end - start)

@@ -10,8 +10,10 @@ Differences a caller can observe, all by design:
   * ``create_tasks`` accepts B >= 1 episodes (the reference squeezes B == 1, model.py:81) and returns
     an opaque :class:`GeneratedWeights` handle that owns the device arena; ``.to_pytree()`` gives the
     reference's ``base_params`` pytree back.
-  * the per-step intermediates (every attention map, base_vit.py:117-118) are not materialised;
-    ``sample_actions`` returns ``{"gripper_logits": ...}`` as its second value.
+  * of the per-step intermediates (every attention map, base_vit.py:117-118) the two slices a caller of the path reads
+    (data/utils/hypervla_interface.py:208-217) are materialised on request: ``sample_actions(..., attention_maps=True)``
+    adds ``"dino_cls_attention"`` [B, 12, 12, P] and ``"head_attention"`` [B, 4, 4, P] to its second value, which
+    otherwise is ``{"gripper_logits": ...}``.
   * arrays may be numpy (copied to the device) or torch CUDA tensors (used in place); results come
     back in the same kind.
 
@@ -284,9 +286,11 @@ class HyperVLA:
 
     def sample_actions(self, images, instruction_dict=None, task=None, timestep_pad_mask=None,
                        base_params: GeneratedWeights = None, train: bool = False, rng=None,
-                       image_embeddings=None):
+                       image_embeddings=None, attention_maps: bool = False):
         """hypervla/model.py:85-137.  images uint8 [B, 1, H, W, 3] (or [B, H, W, 3]) -> actions
-        [B, horizon, action_dim]."""
+        [B, horizon, action_dim].  `attention_maps=True` also returns the two attention slices the reference's wrapper keeps
+        from the intermediates (hypervla_interface.py:208-217): DINOv2's CLS-query attention over the patches, every layer and
+        head, and the generated policy's action-token attention over the patches."""
         torch = _torch()
         if train:
             # train=True switches on nn.Dropout(dropout_rate) (base_vit.py:205, transformer.py:67,74,192,244) and the
@@ -312,11 +316,20 @@ class HyperVLA:
             raise ValueError(f"Input image size must be {g.image_size}x{g.image_size}: got {tuple(img.shape)} for B={B}")
         actions = torch.empty(B, g.horizon, g.action_dim, dtype=torch.float32, device=self.device)
         logits = torch.empty(B, g.horizon, dtype=torch.float32, device=self.device)
-        self._ctx.step(base_params._h, img.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, self._stream())
+        inter = {"gripper_logits": logits}
+        if attention_maps:
+            inter["dino_cls_attention"] = torch.empty(B, g.enc_layers, g.enc_heads, g.patches, dtype=torch.float32, device=self.device)
+            inter["head_attention"] = torch.empty(B, g.layers, g.heads, g.patches, dtype=torch.float32, device=self.device)
+            self._ctx.set_attention_outputs(inter["dino_cls_attention"].data_ptr(), inter["head_attention"].data_ptr())
+        try:
+            self._ctx.step(base_params._h, img.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, self._stream())
+        finally:
+            if attention_maps:
+                self._ctx.set_attention_outputs(0, 0)
         if as_torch:
-            return actions, {"gripper_logits": logits}
+            return actions, inter
         torch.cuda.current_stream(self.device).synchronize()
-        return actions.cpu().numpy(), {"gripper_logits": logits.cpu().numpy()}
+        return actions.cpu().numpy(), {k: v.cpu().numpy() for k, v in inter.items()}
 
     # stage-level entry points (policy-only variant of BASELINE config 2, parity tests)
     def encode_images(self, images):

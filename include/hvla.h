@@ -119,6 +119,18 @@ int hvla_encode_hidden(hvla_ctx* ctx, const uint8_t* images, float* hidden, int3
 int hvla_policy(hvla_ctx* ctx, const hvla_weights* w, const float* tokens, float* actions,
                 float* gripper_logits, int32_t B, void* stream);
 
+/* Replaces: the `intermediates` that sample_actions returns next to the actions (hypervla/model.py:126-137: every attention
+ * map, sown at hypervla/components/base_vit.py:117-118 and by flax's attention modules), as far as a caller of the path
+ * reads them: InferenceWrapper(save_attention_map=True) keeps exactly two slices
+ * (data/utils/hypervla_interface.py:208-217), which the evaluators pickle (data/simpler/evaluate.py:358-378):
+ *   dino_cls_attention f32 [B, enc_layers, enc_heads, P]  DINOv2: attention of the CLS query over the P patch keys
+ *                                                          (`DINO_attention_map[0][layer][b, :, 0, 1:]`)
+ *   head_attention     f32 [B, layers, heads, P]          generated policy: attention of the action token over the P patch
+ *                                                          keys (`attention_weights[0][b, :, -1, :-1]`)
+ * Opt-in: the DEVICE buffers registered here (either may be NULL) are written by every following hvla_encode /
+ * hvla_policy / hvla_step on this ctx until the call is repeated with NULLs; rows are the episodes of that call.   */
+int hvla_set_attention_outputs(hvla_ctx* ctx, float* dino_cls_attention, float* head_attention);
+
 /* Replaces: HyperVLA.sample_actions (hypervla/model.py:85-137): hvla_encode + hvla_policy through
  * the ctx's own token workspace.  B must equal hvla_weights_batch(w).                           */
 int hvla_step(hvla_ctx* ctx, const hvla_weights* w, const uint8_t* images, float* actions,

@@ -342,6 +342,40 @@ def test_hf_torch_dinov2_state_dict_through_the_encoder(tmp_path):
     assert hid.shape == (3, 257, 768) and np.sqrt((d * d).mean()) <= 1e-3 and np.abs(d).max() <= 1e-2, (np.sqrt((d * d).mean()), np.abs(d).max())
 
 
+def test_attention_maps_against_the_oracle(full):
+    """The two attention slices `InferenceWrapper(save_attention_map=True)` keeps (data/utils/hypervla_interface.py:208-217):
+    DINOv2's CLS-query attention over the patches [B, 12, 12, 256] and the generated policy's action-token attention over
+    the patches [B, 4, 4, 256], opt-in outputs of the step (hvla_set_attention_outputs), against the float64 oracle; and
+    asking for them changes no action bit."""
+    from hypervla.config import encoder_leaves, generated_leaves
+    from hypervla.interface import InferenceWrapper
+    from oracle import hvla_ref_np as onp
+    m, g, B = full["model"], full["g"], 2
+    ins = {"language_instruction": {k: v[:B] for k, v in full["ins"]["language_instruction"].items()}}
+    st = {"patch_embeddings": full["st"]["patch_embeddings"][:B]}
+    im = full["im"][:B]
+    w, tasks, _ = m.create_tasks(instruction_dict=ins, initial_state=st)
+    act0, _ = m.sample_actions(im, ins, tasks, np.ones((B, 1)), w)
+    act, inter = m.sample_actions(im, ins, tasks, np.ones((B, 1)), w, attention_maps=True)
+    assert np.array_equal(act, act0)
+    bp, _ = onp.create_tasks(m.params, g, generated_leaves(g), ins, st)
+    dino, head = onp.attention_maps(m.params, g, dict(encoder_leaves(g)), bp, im)
+    assert inter["dino_cls_attention"].shape == dino.shape == (B, 12, 12, 256) and inter["head_attention"].shape == head.shape == (B, 4, 4, 256)
+    dd, dh = np.abs(inter["dino_cls_attention"] - dino), np.abs(inter["head_attention"] - head)
+    print("attention maps: DINOv2 CLS row max |d| %.2e (max weight %.2e), action row max |d| %.2e (max weight %.2e)"
+          % (dd.max(), dino.max(), dh.max(), head.max()))
+    # weights are <= 1, a uniform row is 1 / 257 = 3.9e-3.  The DINOv2 row sits at the fp16 operand noise (1e-5); the action
+    # row is peaked (largest weight 0.3) and carries the token error of the whole encoder in its logits (3e-4 measured)
+    assert dd.max() <= 1e-4 and dh.max() <= 1e-3
+    assert np.abs(inter["head_attention"].sum(-1) + 0 - head.sum(-1)).max() <= 1e-3
+    wr = InferenceWrapper(m, policy_setup="widowx_bridge", horizon=1, pred_action_horizon=4, image_size=224, save_attention_map=True)
+    one = {"language_instruction": {k: v[:1] for k, v in ins["language_instruction"].items()}}
+    wr.reset("t", one, {"patch_embeddings": st["patch_embeddings"][:1]})
+    wr.step(im[0, 0])
+    assert wr.dino_attention_map.shape == (12, 12, 256) and wr.head_attention_map.shape == (4, 4, 256)
+    assert np.abs(wr.dino_attention_map - dino[0]).max() <= 1e-4 and np.abs(wr.head_attention_map - head[0]).max() <= 1e-3
+
+
 def test_inference_wrapper_episode(full):
     from hypervla.interface import InferenceWrapper
     m, g = full["model"], full["g"]
