@@ -14,11 +14,18 @@ for B in Bs:
     w, _, _ = m.create_tasks(instruction_dict=ins, initial_state=st)
     tok = m.encode_images(im)
     ref_a, ref_l = [t.clone() for t in m.policy_from_tokens(tok, w)]
-    runs = max(30, 7680 // B)
+    runs = max(30, int(os.environ.get('HVLA_PROBE_EPISODE_RUNS', '7680')) // B)
     bad, worst = 0, 0.0
     for it in range(runs):
         a, l = m.policy_from_tokens(tok, w)
         d = (a - ref_a).abs().reshape(B, -1).max(1).values
         bad += int((d > 0).sum())
         worst = max(worst, float(d.max()))
-    print(f"B={B}: {runs} runs, episode-runs that differ from the first run: {bad} of {runs * B}, worst |d action| {worst:.2e}")
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for it in range(50):
+        m.policy_from_tokens(tok, w)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 50 * 1e3
+    print(f"B={B}: {runs} runs, episode-runs that differ from the first run: {bad} of {runs * B}, worst |d action| {worst:.2e}; {ms:.4f} ms per launch")
