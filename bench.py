@@ -26,7 +26,7 @@ for p in (os.path.join(ROOT, "hyper-vla_amd"), ROOT):
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-PMC_ROUND = "r2"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
+PMC_ROUND = "r3"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
 PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 

@@ -80,10 +80,13 @@ __device__ __forceinline__ float wave_xor_sum32(float v) {
 }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-  // flax nn.gelu(approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  // flax nn.gelu(approximate=True): 0.5 x (1 + tanh(u)),  u = sqrt(2/pi) (x + 0.044715 x^3).
+  // 0.5 (1 + tanh u) = 1 / (1 + exp(-2 u)): one v_exp_f32 and one v_rcp_f32 instead of libm's tanhf (about 25 instructions,
+  // and this sits on every hidden value of the generated policy, whose kernel is VALU-bound).  |error| ~ 1e-7 relative:
+  // exp2 overflows to +inf for u < -44 (result -0.0 x ... = 0) and underflows to 0 for large u (result x), both the limits.
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  const float u = k0 * (x + k1 * x * x * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u));
 }
 // exact-erf GELU (HF ACT2FN["gelu"]).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 round-off level)
 // instead of libm erff, which matters because the fc1 epilogue applies it to B*257*3072 values per layer with the matrix

@@ -32,9 +32,9 @@ static uint16_t f2bf(float f) {
 
 template <int TIE>
 static int run_variant(const PolicyParams& p, int launches, bool loaded, const float4* sa, float4* sb, size_t sn) {
-  constexpr int NW = 8, SP = (NW + 1) * 32, VLD = SP + 8;
-  const size_t smem = (size_t)PRING * 8192 + ((size_t)2 * 2 * SP * 16 + (size_t)2 * 32 * VLD) * sizeof(__bf16) + (size_t)(NW + 1) * 4096 +
-                      (size_t)(p.pl.Gv - p.pl.v_layer0) * sizeof(float);
+  constexpr int NW = 8, SP = NW * 32, VLD = SP + 8;           // the eight-wave kernel of round 3 (launch_policy_nw in csrc/policy.hip)
+  const size_t smem = (size_t)PRING * 8192 + ((size_t)2 * 2 * SP * 16 + (size_t)2 * 32 * VLD) * sizeof(__bf16) + (size_t)NW * 4096 +
+                      (size_t)(p.pl.Gv - p.pl.v_layer0) * sizeof(float) + (size_t)(((384 + 2 * 9 * 20 + NW * 32 + 2 * SP) * 4 + 1023) & ~1023);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_kernel<NW, TIE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const size_t nact = (size_t)p.B * p.horizon * p.action_dim;
   std::vector<float> first(nact), cur(nact);
@@ -43,7 +43,7 @@ static int run_variant(const PolicyParams& p, int launches, bool loaded, const f
   int differing = 0;
   for (int it = 0; it < launches; ++it) {
     if (loaded) hipLaunchKernelGGL(stream_kernel, dim3(512), dim3(256), 0, s2, sa, sb, sn);
-    hipLaunchKernelGGL((policy_kernel<NW, TIE>), dim3(p.B), dim3((NW + 1) * 64), smem, 0, p);
+    hipLaunchKernelGGL((policy_kernel<NW, TIE>), dim3(p.B), dim3(NW * 64), smem, 0, p);
     CK(hipMemcpy(it ? cur.data() : first.data(), p.actions, nact * 4, hipMemcpyDeviceToHost));
     if (it && memcmp(cur.data(), first.data(), nact * 4)) ++differing;
   }
