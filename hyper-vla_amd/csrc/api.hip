@@ -155,8 +155,8 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   A(ctx->ctx_hi, Bm * g.C * 2); A(ctx->ctx_lo, Bm * g.C * 2); A(ctx->ctx_f32, Bm * g.C * 4);
   A(ctx->ws_x, Bm * S * E * 4); A(ctx->ws_h, Bm * S * E * 2); A(ctx->ws_qkv, Bm * S * 3 * E * 2);
   A(ctx->ws_g, gbytes); A(ctx->tokens, Bm * P * E * 4); A(ctx->flags, 64 * sizeof(int));
-  A(ctx->ws_corr, Bm * (F > 3 * E ? F : 3 * E) * 4);
-  A(ctx->ws_abar, Bm * (F > E ? F : E) * 2);
+  A(ctx->ws_corr, 2 * Bm * (F > 3 * E ? F : 3 * E) * 4);      // two rows per image (upper / lower half): encoder.hip GemmArgs::corr
+  A(ctx->ws_abar, 2 * Bm * (F > E ? F : E) * 2);
   if (e != hipSuccess) return HVLA_E_ARENA_FULL;
   if (c->streams == 2) {
     if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
@@ -474,8 +474,8 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
   const size_t gper = S * F > (size_t)g.P() * ctx->Kp ? S * F : (size_t)g.P() * ctx->Kp;
   EncWorkspace ws{ctx->ws_x.as<float>() + rows * E, static_cast<char*>(ctx->ws_h.p) + rows * E * 2,
                   static_cast<char*>(ctx->ws_qkv.p) + rows * 3 * E * 2, static_cast<char*>(ctx->ws_g.p) + (size_t)b0 * gper * 2,
-                  ctx->ws_corr.as<float>() + (size_t)b0 * (F > 3 * E ? F : 3 * E),
-                  static_cast<char*>(ctx->ws_abar.p) + (size_t)b0 * (F > E ? F : E) * 2};
+                  ctx->ws_corr.as<float>() + (size_t)2 * b0 * (F > 3 * E ? F : 3 * E),
+                  static_cast<char*>(ctx->ws_abar.p) + (size_t)2 * b0 * (F > E ? F : E) * 2};
   if (ctx->amap_dino) ws.amap = ctx->amap_dino + (size_t)b0 * g.enc_layers * g.enc_heads * g.P();
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,

@@ -91,18 +91,24 @@ struct GemmArgs {
   int P, S;              // patches / tokens per image (PATCH row remap; row -> image)
   int qcols;             // QKV: columns < qcols are scaled by qscale
   float qscale;
-  const float* corr = nullptr;   // [B][N] per-image bias row = bias + (mean row of A over the image) . dW; rows that are an
-                                 // image's CLS token keep the plain bias (one token of 257: nothing coherent to compensate)
+  const float* corr = nullptr;   // [B][2][N] bias rows per image HALF = bias + (mean row of A over that half of the image) . dW;
+                                 // rows that are an image's CLS token keep the plain bias (one token of 257: nothing coherent
+                                 // to compensate).  Two halves (round 3): on camera-like frames the coherent part of the weight
+                                 // rounding differs between the upper and the lower half of the picture; the float64 study
+                                 // (tests/studies/precision_budget.py --study hilo) puts the worst action error of 64 structured
+                                 // episodes at 7.1e-4 with two mean rows against 1.0e-3 with one (finer bands add nothing)
   // gemm64_kernel, second problem in the same launch (blocks >= nb1): corr2[M2][N] = bias + abar2[M2][K] . dW2[N][K] / 4096
   const void* abar2 = nullptr;
   const void* dW2 = nullptr;
   float* corr2 = nullptr;
   int M2 = 0, nb1 = 0;
   int row0 = 0, row_step = 1;    // gemm64_kernel: the B CLS rows are rows b * S of the activation matrix
+  int hsplit = 1 << 30;          // corr tables have TWO rows per image: [image][half][N], half = (token index >= hsplit); the
+                                 // host sets 1 + P / 2 (tokens 1 .. P/2 | P/2 + 1 .. P: the two wave rows of an image-aligned tile)
   // gemm256p_kernel: tile row t covers global rows tile_row0 + t * tile_stride .. + 255 (image-aligned: 1, S; the patch
   // GEMM's contiguous rows: 0, 256); nbm tile rows, every tile full
   int tile_row0 = 0, tile_stride = 256, nbm = 0;
-  void* colmean = nullptr;       // GELU, image-aligned tiles only: [B][N] 16-bit mean over the tile's 256 rows of its rounded outputs
+  void* colmean = nullptr;       // GELU, image-aligned tiles only: [B][2][N] 16-bit mean over each wave row's 128 rows of its rounded outputs
 };
 
 // Row-major epilogue shared by the three GEMM kernels.  They run the MFMA with the activation fragment as the first
@@ -164,13 +170,14 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
         if constexpr (ROWBIAS) {
           brow[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
           const int img = grow / g.S;
+          const int tok = grow - img * g.S, hf = tok >= g.hsplit ? 1 : 0;      // table row = (image, half)
           if (lds_img0 >= 0) {                             // wave-uniform: the table was computed by this workgroup (gemm64c_kernel)
             if (ok[u][r]) {
-              if (grow - img * g.S) brow[u][r] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds_corr + (img - lds_img0) * 64 + 4 * fr);
+              if (tok) brow[u][r] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds_corr + ((img - lds_img0) * 2 + hf) * 64 + 4 * fr);
               else brow[u][r] = *reinterpret_cast<const f32x4*>(g.bias + (uint32_t)n);      // CLS row: plain bias
             }
           } else {
-            const float* bsrc = grow - img * g.S ? g.corr + (uint32_t)img * (uint32_t)g.N : g.bias;   // CLS row: plain bias
+            const float* bsrc = tok ? g.corr + (uint32_t)(img * 2 + hf) * (uint32_t)g.N : g.bias;   // CLS row: plain bias
             if (ok[u][r]) brow[u][r] = *reinterpret_cast<const f32x4*>(bsrc + (uint32_t)n);
           }
         }
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
 }
 
 // gemm64c_kernel -- gemm64_kernel for a SMALL batch (all rows, up to 2047) with the per-image bias rows computed inside:
-// the workgroup's 64 rows belong to at most 16 images (two at S = 257); their mean rows against the block's 64 columns of
+// the workgroup's 64 rows belong to at most 8 images (two at S = 257: four (image, half) mean rows); those against the block's 64 columns of
 // dW are one more 16-row MFMA tile over the same K loop (wave w takes n-tile w: two MFMAs per K-tile and wave), staged
 // beside A and W (dW 8 KB, mean rows 4 KB per stage).  The accumulators go through corr_value() into a 16 x 64 table in LDS
 // that the epilogue reads instead of a table in memory: the separate table launch in front of every GEMM (48 per step,
@@ -460,9 +467,9 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     woff[j] = (uint32_t)(n0 + wperm(rl)) * (uint32_t)g.K + sch;
   }
   {
-    int img = img0 + 8 * wave + (lane >> 3);                  // rows 0..31 of the mean-row tile; the MFMA reads rows 0..15
-    img = img < g.M2 ? img : g.M2 - 1;
-    boff = (uint32_t)img * (uint32_t)g.K + sch;
+    int mr = img0 * 2 + 8 * wave + (lane >> 3);               // rows 0..31 of the mean-row tile = (image, half) pairs from image
+    mr = mr < g.M2 ? mr : g.M2 - 1;                           // img0 on (M2 = 2 B rows); the MFMA reads rows 0..15
+    boff = (uint32_t)mr * (uint32_t)g.K + sch;
   }
   const int KT = g.K / 64;
   auto issue = [&](int kt) {
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
       acc2 = Op::mma16(fb[kk], fd[kk], acc2);
     }
   }
-  // acc2[r] = (mean row of image img0 + 4 fq + r) . dW[:, n0 + 4 fr + wave] x 4096  ->  table[image - img0][4 fr + wave]
+  // acc2[r] = (mean row 2 img0 + 4 fq + r) . dW[:, n0 + 4 fr + wave] x 4096  ->  table[(image - img0) * 2 + half][4 fr + wave]
   __builtin_amdgcn_s_barrier();                      // every wave is done with the last stage: its space takes the table
   float* table = reinterpret_cast<float*>(smem);
   {
@@ -706,7 +713,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
-  int tcount = 0, ptm = 0, pn0 = 0;                 // GELU column means: tiles done by this workgroup, the previous tile
   while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     // bias row (per image when a corr table is given: an image-aligned tile row IS an image) / LayerScale of this tile
     // are fetched and WAITED FOR before the next tile's DMA goes out: the compiler does not see the hand-issued DMA, so a
     // wait it places after that point is a vmcnt(0) that would drain the prefetch
-    const float* brow = (EPI != EPI_PATCH && g.corr) ? g.corr + (size_t)ctm * g.N : g.bias;
+    const float* brow = (EPI != EPI_PATCH && g.corr) ? g.corr + ((size_t)ctm * 2 + wm) * g.N : g.bias;   // this wave row's half of the image
     f32x4 pb4 = *reinterpret_cast<const f32x4*>(brow + cn0 + wn * 64 + 4 * fr), pl4 = pb4;
     if constexpr (EPI == EPI_RES) pl4 = *reinterpret_cast<const f32x4*>(g.aux + cn0 + wn * 64 + 4 * fr);
     asm volatile("" : "+v"(pb4), "+v"(pl4));
@@ -746,33 +752,22 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     }
     if constexpr (EPI == EPI_GELU) {
       if (g.colmean) {
-        // mean row of this tile's rounded outputs for the fc2 compensation: lane sums its 32 rows (ascending, in the
-        // operand type), the four lanes that share the columns combine in f32 as (fq0 + fq1) + (fq2 + fq3), and each wave
-        // row parks its half in the 4 KB of LDS behind the K-loop buffers.  The two halves are added (half0 + half1) one
-        // tile LATER, when dozens of barriers have made them visible: no barrier in the epilogue, which would line the two
-        // wave rows up and undo their stagger.
+        // mean rows of this tile's rounded outputs for the fc2 compensation, one per WAVE ROW (= half of the image): lane sums
+        // its 32 rows (ascending, in the operand type), the four lanes that share the columns combine in f32 as
+        // (fq0 + fq1) + (fq2 + fq3), and the wave writes its 64 columns of row (image, wave row) itself -- no LDS, no barrier.
         typename Op::x4 csh;
 #pragma unroll
         for (int c = 0; c < 4; ++c) csh[c] = (T)0.f;
         gemm_epilogue_rows_impl<Op, EPI, 8, true, false, true>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4, &csh);
-        f32x4 cs;
+        typename Op::x4 mo;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          cs[c] = (float)csh[c];
-          cs[c] += __shfl_xor(cs[c], 16, 64);
-          cs[c] += __shfl_xor(cs[c], 32, 64);
+          float cs = (float)csh[c];
+          cs += __shfl_xor(cs, 16, 64);
+          cs += __shfl_xor(cs, 32, 64);
+          mo[c] = (T)(cs * (1.f / 128.f));
         }
-        f32x4* park = reinterpret_cast<f32x4*>(smem + 131072);          // [parity][wave row][wn][fr]
-        if (fq == 0) park[((tcount & 1) * 2 + wm) * 64 + wn * 16 + fr] = cs;
-        if (tcount > 0 && wm == 0 && fq == 0) {                          // the previous tile of this workgroup
-          const int pp = (tcount - 1) & 1;
-          const f32x4 tot = park[(pp * 2 + 0) * 64 + wn * 16 + fr] + park[(pp * 2 + 1) * 64 + wn * 16 + fr];
-          typename Op::x4 mo;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) mo[c] = (T)(tot[c] * (1.f / 256.f));
-          *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.colmean) + (size_t)ptm * g.N + pn0 + wn * 64 + 4 * fr) = mo;
-        }
-        ptm = ctm; pn0 = cn0; ++tcount;
+        if (fq == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.colmean) + ((size_t)ctm * 2 + wm) * g.N + cn0 + wn * 64 + 4 * fr) = mo;
       } else {
         gemm_epilogue_rows_impl<Op, EPI, 8, true, false>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
       }
@@ -788,21 +783,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     static_assert(WAITN >= 63 || WAITN == 36, "the s_waitcnt immediates below are written for these two counts");
     if constexpr (WAITN >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
-  }
-  if constexpr (EPI == EPI_GELU) {
-    if (g.colmean && tcount > 0) {                   // the last tile's halves: one barrier at the very end
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      HVLA_BAR();
-      if (wm == 0 && fq == 0) {
-        const f32x4* park = reinterpret_cast<const f32x4*>(smem + 131072);
-        const int pp = (tcount - 1) & 1;
-        const f32x4 tot = park[(pp * 2 + 0) * 64 + wn * 16 + fr] + park[(pp * 2 + 1) * 64 + wn * 16 + fr];
-        typename Op::x4 mo;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mo[c] = (T)(tot[c] * (1.f / 256.f));
-        *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.colmean) + (size_t)ptm * g.N + pn0 + wn * 64 + 4 * fr) = mo;
-      }
-    }
   }
 #undef HVLA_BAR
 }
@@ -947,25 +927,27 @@ __device__ __forceinline__ void ln_row(const f32x4 (&cur)[4], const f32x4 (&s4)[
 template <typename Op>
 __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                 typename Op::elem* __restrict__ abar, int S, int E) {
+                                                                 typename Op::elem* __restrict__ abar, int S, int E, int hsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [LNW][E / 4]
+  f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [2 halves][LNW][E / 4]
   const int b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n4 = E / 4;
-  f32x4 cs[4], cur[4], nxt[4], s4[4], b4[4];
+  f32x4 cs[4], cs1[4], cur[4], nxt[4], s4[4], b4[4];                 // cs: rows [0, hsplit), cs1: rows [hsplit, S)
   auto load = [&](f32x4 (&v)[4], int row) {
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((size_t)b * S + (row < S ? row : S - 1)) * E);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int col = lane + 64 * i;
-      v[i] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
+      // non-temporal: x is not read again before the next residual epilogue, a whole GEMM later; kept out of the way, the
+      // 16-bit rows this kernel writes stay closer to the GEMM that reads them next (QKV 2.52 -> 2.47 ms per step)
+      v[i] = col < n4 ? __builtin_nontemporal_load(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int col = lane + 64 * i;
-    cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cs[i] = cs1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     s4[i] = col < n4 ? reinterpret_cast<const f32x4*>(scale)[col] : cs[i];
     b4[i] = col < n4 ? reinterpret_cast<const f32x4*>(bias)[col] : cs[i];
   }
@@ -974,23 +956,31 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __
     load(nxt, row + LNW);
     f32x4 y[4];
     ln_row<Op>(cur, s4, b4, n4, E, lane, out + ((size_t)b * S + row) * E, y);
+    if (row < hsplit) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cs[i] += y[i], cur[i] = nxt[i];
+      for (int i = 0; i < 4; ++i) cs[i] += y[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cs1[i] += y[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
   }
   if (!abar) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    if (lane + 64 * i < n4) red[wave * n4 + lane + 64 * i] = cs[i];
+    if (lane + 64 * i < n4) red[wave * n4 + lane + 64 * i] = cs[i], red[(LNW + wave) * n4 + lane + 64 * i] = cs1[i];
   __syncthreads();
-  if ((int)threadIdx.x < n4) {
-    f32x4 t = red[threadIdx.x];
+  if ((int)threadIdx.x < 2 * n4) {                                   // threads [0, n4): half 0, [n4, 2 n4): half 1
+    const int hf = (int)threadIdx.x >= n4, c4 = threadIdx.x - hf * n4;
+    f32x4 t = red[hf * LNW * n4 + c4];
 #pragma unroll
-    for (int w = 1; w < LNW; ++w) t += red[w * n4 + threadIdx.x];
-    const float inv = 1.f / (float)S;
+    for (int w = 1; w < LNW; ++w) t += red[(hf * LNW + w) * n4 + c4];
+    const float inv = 1.f / (float)(hf ? S - hsplit : hsplit);
     typename Op::x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (typename Op::elem)(t[j] * inv);
-    reinterpret_cast<typename Op::x4*>(abar + (size_t)b * E)[threadIdx.x] = o;
+    reinterpret_cast<typename Op::x4*>(abar + ((size_t)b * 2 + hf) * E)[c4] = o;
   }
 }
 
@@ -1002,7 +992,7 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __
 template <typename Op>
 __global__ __launch_bounds__(LNW * 64) void layernorm_split_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
                                                                    const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                   float* __restrict__ partial, int S, int E) {
+                                                                   float* __restrict__ partial, int S, int E, int hsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* ys = reinterpret_cast<f32x4*>(smem);                        // [rows of this workgroup][E / 4]
   const int j = blockIdx.x, b = blockIdx.y;
@@ -1035,26 +1025,28 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_split_kernel(const float* 
   }
   if (!partial) return;
   __syncthreads();
-  if ((int)threadIdx.x < n4) {
+  if ((int)threadIdx.x < 2 * n4) {                                   // partial[b][half][j][E]: the rows of "wave j" that lie in that half
+    const int hf = (int)threadIdx.x >= n4, c4 = threadIdx.x - hf * n4;
     f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int v = 0; v < nrows; ++v) cs += ys[v * n4 + threadIdx.x];
-    reinterpret_cast<f32x4*>(partial + ((size_t)b * LNW + j) * E)[threadIdx.x] = cs;
+    for (int v = 0; v < nrows; ++v)
+      if ((j + LNW * v >= hsplit) == (hf != 0)) cs += ys[v * n4 + c4];
+    reinterpret_cast<f32x4*>(partial + (((size_t)b * 2 + hf) * LNW + j) * E)[c4] = cs;
   }
 }
 template <typename Op>
 __global__ __launch_bounds__(256) void layernorm_mean_kernel(const float* __restrict__ partial, typename Op::elem* __restrict__ abar,
-                                                             int S, int E) {
-  const int b = blockIdx.x, n4 = E / 4;
+                                                             int S, int E, int hsplit) {
+  const int bh = blockIdx.x, n4 = E / 4;                             // (image, half)
   if ((int)threadIdx.x >= n4) return;
-  const f32x4* p = reinterpret_cast<const f32x4*>(partial + (size_t)b * LNW * E);
+  const f32x4* p = reinterpret_cast<const f32x4*>(partial + (size_t)bh * LNW * E);
   f32x4 t = p[threadIdx.x];
 #pragma unroll
   for (int w = 1; w < LNW; ++w) t += p[w * n4 + threadIdx.x];
-  const float inv = 1.f / (float)S;
+  const float inv = 1.f / (float)((bh & 1) ? S - hsplit : hsplit);
   typename Op::x4 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = (typename Op::elem)(t[j] * inv);
-  reinterpret_cast<typename Op::x4*>(abar + (size_t)b * E)[threadIdx.x] = o;
+  reinterpret_cast<typename Op::x4*>(abar + (size_t)bh * E)[threadIdx.x] = o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1137,7 +1129,8 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
 #pragma unroll
     for (int j = 0; j < 8; ++j) kreg[it][j] = (T)0.f;
-    if (i < SP * 8 && key < S) kreg[it] = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + E + ch * 8);
+    // (K and V are read exactly once per step: non-temporal loads, 1.88 -> 1.84 ms per step)
+    if (i < SP * 8 && key < S) kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const X8*>(base + (size_t)key * rowstride + E + ch * 8));
   }
 #pragma unroll
   for (int it = 0; it < STG; ++it) {
@@ -1145,7 +1138,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
 #pragma unroll
     for (int j = 0; j < 8; ++j) vreg[it][j] = (T)0.f;
-    if (i < SP * 8 && key < S) vreg[it] = *reinterpret_cast<const X8*>(base + (size_t)key * rowstride + 2 * E + ch * 8);
+    if (i < SP * 8 && key < S) vreg[it] = __builtin_nontemporal_load(reinterpret_cast<const X8*>(base + (size_t)key * rowstride + 2 * E + ch * 8));
   }
 #pragma unroll
   for (int it = 0; it < STG; ++it) {
@@ -1328,10 +1321,14 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     }
     const float last = od / L;
     o[((size_t)b * S + (S - 1)) * E + head * 64 + lane] = (T)last;
-    if (omean) {
-      float t = csum[lane];
-      for (int w = 1; w < NW; ++w) t += csum[w * 64 + lane];
-      omean[(size_t)b * E + head * 64 + lane] = (T)((t + last) / (float)S);
+    if (omean) {               // [image][half][E]: tokens [0, 32 NW / 2) and the rest (the wave split; half a wave's width off the
+      const int NH = NW / 2;   // consumer's token split for odd NW, one token off at S = 257: the mean only needs per cents)
+      float t0 = 0.f, t1 = last;
+      for (int w = 0; w < NH; ++w) t0 += csum[w * 64 + lane];
+      for (int w = NH; w < NW; ++w) t1 += csum[w * 64 + lane];
+      if (NH == 0) t0 = t1;                                  // one wave (tiny geometries): both rows carry the whole image's mean
+      omean[((size_t)b * 2 + 0) * E + head * 64 + lane] = (T)(t0 / (float)(NH ? NH * 32 : S));
+      omean[((size_t)b * 2 + 1) * E + head * 64 + lane] = (T)(t1 / (float)(NH ? S - NH * 32 : S));
     }
   }
   HVLA_ASTAMP();                                           // 7 end
@@ -1346,8 +1343,8 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 // the table only needs the mean to a few per cent), summed as two halves so that gemm256p_kernel's GELU epilogue can produce the
 // same numbers for its own outputs (same values, same order of additions => same bits; the batch-invariance tests cross
 // the two): half wm = rows [wm P/2, +P/2) of the image; inside a half, quad q (rows 4q..4q+3) goes to partial q & 3, each
-// partial adds its values in ascending row order IN THE 16-BIT TYPE, the half is (p0 + p1) + (p2 + p3) in f32, and the
-// mean is (half0 + half1) / P rounded to the operand type.
+// partial adds its values in ascending row order IN THE 16-BIT TYPE, the half is (p0 + p1) + (p2 + p3) in f32, and each
+// half's mean (half / (P / 2), rounded to the operand type) is one row of the table [image][half][K].
 template <typename T>
 __global__ __launch_bounds__(256) void colmean_kernel(const T* __restrict__ a, T* __restrict__ abar, int S, int P, int K) {
   const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
@@ -1366,7 +1363,8 @@ __global__ __launch_bounds__(256) void colmean_kernel(const T* __restrict__ a, T
     }
     hs[wm] = ((float)p[0] + (float)p[1]) + ((float)p[2] + (float)p[3]);
   }
-  abar[(size_t)b * K + n] = (T)((hs[0] + hs[1]) * (1.f / (float)P));
+  abar[((size_t)b * 2 + 0) * K + n] = (T)(hs[0] * (1.f / (float)half));       // [image][half][K], as the GELU epilogue writes it
+  abar[((size_t)b * 2 + 1) * K + n] = (T)(hs[1] * (1.f / (float)half));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1436,6 +1434,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
     SETA((gemm64_kernel<Op, EPI_RES>)) SETA((gemm64_kernel<Op, EPI_CORR>))
     SETA((gemm64_kernel<Op, EPI_QKV, 4>)) SETA((gemm64_kernel<Op, EPI_GELU, 4>)) SETA((gemm64_kernel<Op, EPI_RES, 4>))
+    SETA((gemm64_kernel<Op, EPI_QKV, 3>)) SETA((gemm64_kernel<Op, EPI_GELU, 3>)) SETA((gemm64_kernel<Op, EPI_RES, 3>))
     SETA((gemm64c_kernel<Op, EPI_QKV>)) SETA((gemm64c_kernel<Op, EPI_GELU>)) SETA((gemm64c_kernel<Op, EPI_RES>))
 #undef SETA
     di.attr[opi] = true;
@@ -1445,6 +1444,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   constexpr int G64_MAXM = 2047;       // rows up to which a GEMM is cut into 64x64 tiles (pure latency below that)
   constexpr int CAT_COMP = 8;          // HVLA_PROF_COMP
   const bool comp = w.layer[0].dqkv != nullptr && ws.corr && ws.abar;
+  const int hsplit = 1 + P / 2;        // tokens [1, hsplit) | [hsplit, S): the two wave rows of an image-aligned tile; the CLS row takes the plain bias
   // ---- one GEMM of the encoder: activations [B*S rows][K] -> [B*S rows][N], with the per-image bias rows that compensate
   // the rounding of W (dW = the rounding residue x 4096; the mean row of the activation operand is in ws.abar, written by
   // the kernel that produced the operand)
@@ -1458,6 +1458,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                   void* out, int qcols, int cat, void* colmean = nullptr) -> bool {
     constexpr int EPI = decltype(epic)::value;
     GemmArgs a{A, Wt, M, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
+    a.hsplit = hsplit;
     const bool fits32 = (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
     const bool aligned = P == HBM_ && N % HBN_ == 0 && M > G64_MAXM && K >= 128 && K % 64 == 0 && fits32;
     pf.begin(CAT_COMP, st);
@@ -1466,9 +1467,10 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       c.M = B; c.row0 = 0; c.row_step = S;
       c.nb1 = ((B + SBM - 1) / SBM) * (N / SBN);
       int nblocks = c.nb1;
-      if (comp) { c.abar2 = ws.abar; c.dW2 = dW; c.corr2 = ws.corr; c.M2 = B; nblocks *= 2; }
+      if (comp) { c.abar2 = ws.abar; c.dW2 = dW; c.corr2 = ws.corr; c.M2 = 2 * B; nblocks += ((2 * B + SBM - 1) / SBM) * (N / SBN); }   // two mean rows per image
       if constexpr (EPI != EPI_PATCH) {
-        if (nblocks > ncu) hipLaunchKernelGGL((gemm64_kernel<Op, EPI, 4>), dim3(nblocks), dim3(256), 4 * 16384, st, c);   // two workgroups per CU: one round
+        if (nblocks > 2 * ncu) hipLaunchKernelGGL((gemm64_kernel<Op, EPI, 3>), dim3(nblocks), dim3(256), 3 * 16384, st, c);   // three workgroups per CU
+        else if (nblocks > ncu) hipLaunchKernelGGL((gemm64_kernel<Op, EPI, 4>), dim3(nblocks), dim3(256), 4 * 16384, st, c);   // two workgroups per CU: one round
         else hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
       } else {
         hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
@@ -1477,7 +1479,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       const int nbn = N / HBN_;
       a.corr = comp ? ws.corr : nullptr;
       a.nbm = B; a.tile_row0 = 1; a.tile_stride = S; a.colmean = colmean;
-      const size_t lds = 131072 + (EPI == EPI_GELU ? 4096 : 0);
+      const size_t lds = 131072;
       pf.begin(cat, st);
       if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), lds, st, a);
       else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), lds, st, a);
@@ -1486,7 +1488,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     }
     if constexpr (EPI != EPI_PATCH) {
       if (comp && M <= G64_MAXM && fits32 && N % SBN == 0 && K % 64 == 0 && S >= 5) {     // small batch: the bias rows are computed inside the GEMM
-        a.abar2 = ws.abar; a.dW2 = dW; a.M2 = B;
+        a.abar2 = ws.abar; a.dW2 = dW; a.M2 = 2 * B;
         pf.end(CAT_COMP, st);
         pf.begin(cat, st);
         hipLaunchKernelGGL((gemm64c_kernel<Op, EPI>), dim3(((M + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNSC * SSTC, st, a);
@@ -1495,8 +1497,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       }
     }
     if (comp) {                                        // the same gemm64_body<EPI_CORR> arithmetic as the fused launch above
-      GemmArgs c{ws.abar, dW, B, N, K, bias, nullptr, ws.corr, P, S, 0, 1.f};
-      hipLaunchKernelGGL((gemm64_kernel<Op, EPI_CORR>), dim3(((B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
+      GemmArgs c{ws.abar, dW, 2 * B, N, K, bias, nullptr, ws.corr, P, S, 0, 1.f};
+      hipLaunchKernelGGL((gemm64_kernel<Op, EPI_CORR>), dim3(((2 * B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
       a.corr = ws.corr;
     }
     pf.end(CAT_COMP, st);
@@ -1510,15 +1512,15 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   };
   constexpr int LN_SPLIT_MAXB = 64;    // up to here a LayerNorm is LNW workgroups per image + a finalising launch (same bits)
   auto layernorm = [&](const float* sc, const float* bi) {           // norm1 / norm2 (+ the column sums of the output)
-    if (B <= LN_SPLIT_MAXB && E <= 1024 && (size_t)LNW * E * sizeof(float) <= (size_t)S * F * sizeof(T)) {
-      float* partial = comp ? reinterpret_cast<float*>(ws.g) : nullptr;      // ws.g is free at both LayerNorms: [B][LNW][E] f32
+    if (B <= LN_SPLIT_MAXB && E <= 1024 && (size_t)2 * LNW * E * sizeof(float) <= (size_t)S * F * sizeof(T)) {
+      float* partial = comp ? reinterpret_cast<float*>(ws.g) : nullptr;      // ws.g is free at both LayerNorms: [B][2][LNW][E] f32
       hipLaunchKernelGGL((layernorm_split_kernel<Op>), dim3(LNW, B), dim3(LNW * 64), (size_t)((S + LNW - 1) / LNW) * E * sizeof(float),
-                         st, ws.x, reinterpret_cast<T*>(ws.h), sc, bi, partial, S, E);
-      if (comp) hipLaunchKernelGGL((layernorm_mean_kernel<Op>), dim3(B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), S, E);
+                         st, ws.x, reinterpret_cast<T*>(ws.h), sc, bi, partial, S, E, hsplit);
+      if (comp) hipLaunchKernelGGL((layernorm_mean_kernel<Op>), dim3(2 * B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), S, E, hsplit);
       return;
     }
-    hipLaunchKernelGGL((layernorm_img_kernel<Op>), dim3(B), dim3(LNW * 64), (size_t)LNW * E * sizeof(float), st, ws.x,
-                       reinterpret_cast<T*>(ws.h), sc, bi, comp ? reinterpret_cast<T*>(ws.abar) : nullptr, S, E);
+    hipLaunchKernelGGL((layernorm_img_kernel<Op>), dim3(B), dim3(LNW * 64), (size_t)2 * LNW * E * sizeof(float), st, ws.x,
+                       reinterpret_cast<T*>(ws.h), sc, bi, comp ? reinterpret_cast<T*>(ws.abar) : nullptr, S, E, hsplit);
   };
   auto colmean_of = [&](const void* act, int K) {      // mean row of a GEMM output whose epilogue did not write it (no image-aligned tiles)
     if (!comp) return;

@@ -57,8 +57,8 @@ struct EncWorkspace {
   void* h;         // [B*S, E] 16-bit LN output / attention output
   void* qkv;       // [B*S, 3E] 16-bit
   void* g;         // [B*S, F] 16-bit MLP hidden; also holds the im2col matrix [B*P, Kp]
-  float* corr;     // [B, max(3E, F)] per-image bias row of the current GEMM (bias + mean row . dW)
-  void* abar;      // [B, max(E, F)] 16-bit mean row of the current GEMM's activation operand
+  float* corr;     // [B, 2, max(3E, F)] bias rows of the current GEMM per image half (bias + mean row of that half . dW)
+  void* abar;      // [B, 2, max(E, F)] 16-bit mean rows (upper / lower half of the image) of the current GEMM's activation operand
   float* amap = nullptr;   // nullable: [B, enc_layers, enc_heads, P] attention of the CLS query over the patch keys (opt-in export)
 };
 // optional live timing: a pool of hipEvent pairs tagged with a category (include/hvla.h HVLA_PROF_*)

@@ -75,6 +75,15 @@ def encoder(hp, g, enc_shapes, images_u8, sites, kind="f16", layer_kinds=None, l
             collect[key] = a.mean((0, 1))
         if corr == "dynamic":
             y = y + a.mean(1, keepdim=True) @ (W - Wr(W))
+        elif isinstance(corr, tuple) and corr[0] == "bands":          # ("bands", n, layers): the mean row per band of 256 / n patch rows
+            nb_, lay = corr[1], corr[2]
+            if key[0] in lay:
+                P_ = a.shape[1] - 1
+                mb = a[:, 1:].reshape(a.shape[0], nb_, P_ // nb_, a.shape[2]).mean(2, keepdim=True).expand(-1, -1, P_ // nb_, -1).reshape(a.shape[0], P_, a.shape[2])
+                mrow = torch.cat([a.mean(1, keepdim=True), mb], 1)
+            else:
+                mrow = a.mean(1, keepdim=True)
+            y = y + mrow @ (W - Wr(W))
         elif isinstance(corr, dict):
             y = y + corr[key] @ (W - Wr(W))
         return y
@@ -188,6 +197,14 @@ def main():
                  ("+ fc2 exact, all layers", {(l, "w2") for l in range(Ls)}),
                  ("+ out-proj exact, all layers", {(l, "wo") for l in range(Ls)}),
                  ("+ all exact (activations only)", {(l, m) for l in range(Ls) for m in ("wq", "wo", "w1", "w2")})]
+        Lall = set(range(Ls))
+        for name, cr in (("mean row per 128 rows, all layers", ("bands", 2, Lall)), ("mean row per 64 rows, all layers", ("bands", 4, Lall)),
+                         ("mean row per 16 rows, all layers", ("bands", 16, Lall)), ("mean row per 64 rows, first 3 layers", ("bands", 4, {0, 1, 2})),
+                         ("mean row per 16 rows, first 3 layers", ("bands", 16, {0, 1, 2}))):
+            tok, _ = encoder(hp, g, enc_shapes, im[:, 0], allsites, "f16", corr=cr)
+            act, logit, _ = onp.policy(bp, g, tok.numpy())
+            d = np.abs(act[..., :6] - act0[..., :6])
+            print(f"{name:36s} action MAE {d.mean():.2e} max {d.max():.2e} p99 {np.quantile(d, 0.99):.2e}", flush=True)
         for name, ex in cases:
             tok, _ = encoder(hp, g, enc_shapes, im[:, 0], allsites, "f16", corr="dynamic", exact_w=ex)
             act, logit, _ = onp.policy(bp, g, tok.numpy())

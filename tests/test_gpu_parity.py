@@ -92,7 +92,8 @@ def test_sample_actions_end_to_end(mid):
     act, inter = m.sample_actions(mid["im"], mid["ins"], tasks, np.ones((mid["B"], 1)), w)
     assert act.shape == (mid["B"], 4, 7) and isinstance(act, np.ndarray)
     d = np.abs(act[..., :6] - mid["act"][..., :6])
-    assert d.mean() <= 1e-3 and d.max() <= 8e-3, (d.mean(), d.max())
+    print("MID end to end: action MAE %.3e max %.3e" % (d.mean(), d.max()))
+    assert d.mean() <= 5e-4 and d.max() <= 2e-3, (d.mean(), d.max())
     assert np.abs(inter["gripper_logits"] - mid["logit"]).mean() <= 2e-3
 
 
@@ -244,9 +245,9 @@ def test_full_geometry_against_golden(full):
     act, inter = m.sample_actions(full["im"], full["ins"], tasks, np.ones((B, 1)), w)
     da = np.abs(act[..., :6] - z["actions"][..., :6])
     print("full geometry: action MAE %.3e max %.3e; logit MAE %.3e" % (da.mean(), da.max(), np.abs(inter["gripper_logits"] - z["logits"]).mean()))
-    # 112 numbers: the maximum is a tail draw of the fp16 activation rounding (5e-4 .. 1.04e-3 over this round's kernel
-    # variants); the <= 1e-3 bar is asserted where it is a statistic, on the 64-episode fixtures below
-    assert da.mean() <= 2.5e-4 and da.max() <= 1.5e-3, (da.mean(), da.max())
+    # 112 numbers: the maximum is a tail draw of the fp16 activation rounding (8.2e-4 with round 3's kernels, 5e-4 .. 1.04e-3
+    # over round 2's variants); the north star's 1e-3 is asserted here too and, as a statistic, on the 64-episode fixtures below
+    assert da.mean() <= 2.5e-4 and da.max() <= 1.0e-3, (da.mean(), da.max())
     dl = np.abs(inter["gripper_logits"] - z["logits"])
     assert dl.mean() <= 5e-4
     safe = np.abs(z["logits"]) > 1e-2
@@ -260,8 +261,9 @@ B64_CASES = {
     "full_b64.npz":            ("synthetic",    "noise",      1.0e-3, 2.5e-4),
     "full_b64_trained.npz":    ("trained_like", "noise",      1.0e-3, 2.5e-4),
     # camera-like frames: neighbouring tokens are nearly equal, so the rounding of ACTIVATIONS is correlated across tokens
-    # too; the mean bound holds with the same margin, the largest of the 1536 values is allowed 1.5e-3
-    "full_b64_structured.npz": ("synthetic",    "structured", 1.5e-3, 2.5e-4),
+    # too.  Since round 3 the weight-rounding compensation uses one mean row per HALF image, which is what
+    # the upper / lower halves of such frames differ in: max 7.6e-4 (1.03-1.1e-3 with one mean row), the 1e-3 bound is back
+    "full_b64_structured.npz": ("synthetic",    "structured", 1.0e-3, 2.5e-4),
 }
 
 
