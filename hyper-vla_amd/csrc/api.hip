@@ -129,7 +129,7 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
                   c->enc_dim <= 1024 && c->enc_mlp % 128 == 0 && c->enc_dim / c->enc_heads == 64 &&
                   (P == 256 || P == 64 || P == 32) && c->image_size % c->patch == 0 &&
                   (c->ctx_dim == 128 || c->ctx_dim == 64 || c->ctx_dim == 32) && c->ctx_dim % c->ctx_heads == 0 &&
-                  c->ctx_mlp % 4 == 0 && c->lang_tokens + 2 <= 40 && c->lang_tokens >= 2 && c->lang_dim % 4 == 0 &&
+                  c->ctx_mlp % 16 == 0 && c->lang_tokens + 2 <= 40 && c->lang_tokens >= 2 && c->lang_dim % 4 == 0 &&
                   c->ctx_layers <= CTX_MAX_LAYERS && c->enc_layers <= ENC_MAX_LAYERS && c->layers >= 1 &&
                   c->horizon * (c->action_dim - 1) + c->horizon <= 32 && c->max_batch >= 1 &&
                   (c->enc_dtype == HVLA_ENC_F16 || c->enc_dtype == HVLA_ENC_BF16);
@@ -935,6 +935,8 @@ int hvla_debug_train_gemm_exact(int on) {
   set_train_gemm_exact(on != 0);
   return HVLA_OK;
 }
+// shader-clock stamps of the last context-encoder launch (workgroup 0): see hypernet.hip CTX_STAMP
+int hvla_debug_ctx_stamps(unsigned long long* out) { return debug_ctx_stamps(out) == hipSuccess ? HVLA_OK : HVLA_E_HIP; }
 #endif  // HVLA_BENCH_HOOKS
 
 int hvla_selftest(hvla_ctx* ctx, void* stream) {

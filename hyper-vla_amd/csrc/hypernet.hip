@@ -21,42 +21,125 @@ namespace hvla {
 // context encoder
 // ------------------------------------------------------------------------------------------------
 constexpr int CTX_THREADS = 1024;   // 16 waves: one workgroup (one episode) per CU, so the waves of that one workgroup have to hide each other's latencies
-constexpr int CTX_RG = 20;   // max rows per row-group (S <= 40)
+constexpr int CTX_WAVES = CTX_THREADS / 64;
+constexpr int CTX_RG = 20;   // S <= 2 * CTX_RG = 40 rows: three 16-row MFMA tiles at most
 
-// y[s][n] (+)= sum_k xs[s][k] * W[k][n]   for s in [0,S), n in [0,N); xs in LDS (row stride xs_ld),
-// W global [K][N] (flax kernel layout), result handed to `sink(s, n, value)`.
-template <typename Sink>
-__device__ __forceinline__ void dense_rows(const float* __restrict__ xs, int xs_ld, int S, int K,
-                                           const float* __restrict__ W, int N, Sink sink) {
-  // the S rows are cut into nrg row groups, as many as there are threads for (at least two: CTX_RG rows per thread at most);
-  // an output element is one thread's k = 0 .. K-1 chain whatever the grouping, so the bits do not depend on it
-  int nrg = CTX_THREADS / N;
-  if (nrg < 2) nrg = 2;
-  const int rg = (S + nrg - 1) / nrg;
-  const int items = nrg * N;
-  for (int it = threadIdx.x; it < items; it += CTX_THREADS) {
-    const int n = it % N, g0 = (it / N) * rg;
-    float acc[CTX_RG];
+// y[s][n] = sum_k xs[s][k] * W[k][n]   for s in [0,S), n in [0,N); xs in LDS (row stride xs_ld, == 4 mod 64 words so that
+// the 16 rows x 4 k of one A operand fall in 64 different banks), W global [K][N] (flax kernel layout), result handed to
+// `sink(s, n, value)`.  Exact f32 on the matrix cores: v_mfma_f32_16x16x4_f32 multiplies and accumulates in f32 (lane l
+// supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15] and receives C[4 (l >> 4) + r][l & 15], r = 0..3).
+// One wave takes a 16-column tile of W for ALL row tiles (W is read once per workgroup, the B operand is reused for the two
+// or three row tiles); when N has fewer than 8 column tiles for the 16 waves the k range is cut in two, the upper half's
+// partial sums go through `part` (LDS, [S][part_ld]) and the lower half's waves add them: the order of the additions is
+// fixed, so the bits are reproducible and independent of the batch.
+// an opaque copy of the lane id: address arithmetic derived from it stays inside the block that uses it (hoisted out of the
+// layer loop it becomes a kernel-long live range per call site and the allocator spills)
+__device__ __forceinline__ int lane_here() {
+  int v = threadIdx.x & 63;
+  asm volatile("" : "+v"(v));
+  return v;
+}
+struct Acc3 {
+  f32x4 a0, a1, a2;   // rows 0-15, 16-31, 32-47 of one 16-column tile
+};
+__device__ __forceinline__ void acc3_zero(Acc3& a) {
+  a.a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+  a.a1 = a.a0;
+  a.a2 = a.a0;
+}
+// acc += xs[0:S, kx : kx + klen] @ Wk[0:klen, 16 tc : 16 tc + 16]   (Wk = the first of the klen rows of W; NT row tiles)
+template <int NT>
+__device__ __forceinline__ void mfma_cols_nt(const float* xs, int xs_ld, int S, int kx, const float* __restrict__ Wk, int N,
+                                             int tc, int klen, Acc3& acc) {
+  const int lane = lane_here(), c = lane & 15, kq = lane >> 4;
+  const int r0 = c < S ? c : S - 1, r1 = 16 + c < S ? 16 + c : S - 1, r2 = 32 + c < S ? 32 + c : S - 1;   // clamped rows are never stored
+  const float* wp = Wk + (size_t)kq * N + tc * 16 + c;
+  const float* x0 = xs + r0 * xs_ld + kx + kq;
+  const float* x1 = xs + r1 * xs_ld + kx + kq;
+  const float* x2 = xs + r2 * xs_ld + kx + kq;
+  auto step = [&](float xa, float xb, float xc, float bv) {
+    acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, bv, acc.a0, 0, 0, 0);
+    if (NT > 1) acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, bv, acc.a1, 0, 0, 0);
+    if (NT > 2) acc.a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc, bv, acc.a2, 0, 0, 0);
+  };
+  int k = 0;
+  if (klen >= 32) {
+    // eight k steps per batch; the next batch's W values are requested (L2) before this batch's x values (LDS), and all of a
+    // batch's x values before its first MFMA: the 16 waves of the one workgroup per CU are all there is to hide the round trips
+    float cur[8], nxt[8], xa[8], xb[8], xc[8];
 #pragma unroll
-    for (int r = 0; r < CTX_RG; ++r) acc[r] = 0.f;
-    for (int k = 0; k < K; k += 4) {
-      const float w0 = W[(size_t)(k + 0) * N + n], w1 = W[(size_t)(k + 1) * N + n];
-      const float w2 = W[(size_t)(k + 2) * N + n], w3 = W[(size_t)(k + 3) * N + n];
+    for (int j = 0; j < 8; ++j) cur[j] = wp[(size_t)(4 * j) * N];
+    for (; k + 32 <= klen; k += 32) {
+      const bool more = k + 64 <= klen;
+      if (more) {
 #pragma unroll
-      for (int r = 0; r < CTX_RG; ++r) {
-        if (r < rg) {                          // uniform
-          int row = g0 + r;
-          row = row < S ? row : S - 1;          // clamp: discarded at the sink
-          const f32x4 x = *reinterpret_cast<const f32x4*>(xs + row * xs_ld + k);
-          acc[r] = fmaf(x[0], w0, fmaf(x[1], w1, fmaf(x[2], w2, fmaf(x[3], w3, acc[r]))));
-        }
+        for (int j = 0; j < 8; ++j) nxt[j] = wp[(size_t)(k + 32 + 4 * j) * N];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xa[j] = x0[k + 4 * j];
+        if (NT > 1) xb[j] = x1[k + 4 * j];
+        if (NT > 2) xc[j] = x2[k + 4 * j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) step(xa[j], xb[j], xc[j], cur[j]);
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
       }
     }
+  }
+  for (; k < klen; k += 4) step(x0[k], x1[k], x2[k], wp[(size_t)k * N]);
+}
+__device__ __forceinline__ void mfma_cols(const float* xs, int xs_ld, int S, int kx, const float* __restrict__ Wk, int N,
+                                          int tc, int klen, Acc3& acc) {
+  if (S > 32) mfma_cols_nt<3>(xs, xs_ld, S, kx, Wk, N, tc, klen, acc);
+  else if (S > 16) mfma_cols_nt<2>(xs, xs_ld, S, kx, Wk, N, tc, klen, acc);
+  else mfma_cols_nt<1>(xs, xs_ld, S, kx, Wk, N, tc, klen, acc);
+}
+// f(row, n, value, tile) for the rows < S of a finished tile
+template <typename F>
+__device__ __forceinline__ void acc3_rows(const Acc3& acc, int S, int tc, F f) {
+  const int lane = lane_here(), c = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < CTX_RG; ++r) {
-      const int row = g0 + r;
-      if (r < rg && row < S) sink(row, n, acc[r]);
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * kq + r, n = tc * 16 + c;
+    if (row < S) f(row, n, acc.a0[r]);
+    if (16 + row < S) f(16 + row, n, acc.a1[r]);
+    if (32 + row < S) f(32 + row, n, acc.a2[r]);
+  }
+}
+// the upper-k-half waves leave their sums in `part`, the lower-half waves add them and hand the total to the sink
+template <typename Sink>
+__device__ __forceinline__ void acc3_combine(const Acc3& acc, int S, int tc, int kh, float* part, int part_ld, Sink sink) {
+  if (kh == 1) acc3_rows(acc, S, tc, [&](int row, int n, float v) { part[row * part_ld + n] = v; });
+  __syncthreads();
+  if (kh == 0) acc3_rows(acc, S, tc, [&](int row, int n, float v) { sink(row, n, v + part[row * part_ld + n]); });
+}
+
+// sink(row, n, value + bias[n]): the bias is requested with the tile's first W values, not after its last MFMA
+template <typename Sink>
+__device__ __forceinline__ void dense_mfma(const float* xs, int xs_ld, int S, int K, const float* __restrict__ W, int N,
+                                           const float* __restrict__ bias, float* part, int part_ld, Sink sink) {
+  const int wave = threadIdx.x >> 6;
+  const int ntc = N >> 4;
+  const bool split = part != nullptr && ntc * 2 <= CTX_WAVES && (K & 7) == 0;     // uniform over the workgroup
+  if (!split) {
+    for (int tc = wave; tc < ntc; tc += CTX_WAVES) {
+      Acc3 acc;
+      acc3_zero(acc);
+      const float bn = bias[tc * 16 + (lane_here() & 15)];
+      mfma_cols(xs, xs_ld, S, 0, W, N, tc, K, acc);
+      acc3_rows(acc, S, tc, [&](int row, int n, float v) { sink(row, n, v + bn); });
     }
+  } else {
+    // ntc * 2 <= CTX_WAVES: one task per wave, its sums stay in registers across the barrier
+    const int tc = wave % ntc, kh = wave < 2 * ntc ? wave / ntc : -1, klen = K >> 1;
+    Acc3 acc;
+    acc3_zero(acc);
+    const float bn = bias[tc * 16 + (lane_here() & 15)];
+    if (kh >= 0) mfma_cols(xs, xs_ld, S, kh * klen, W + (size_t)kh * klen * N, N, tc, klen, acc);
+    acc3_combine(acc, S, tc, kh, part, part_ld, [&](int row, int n, float v) { sink(row, n, v + bn); });
   }
 }
 
@@ -83,6 +166,17 @@ __device__ __forceinline__ void ln_rows(const float* xs, float* ys, int ld, int 
   }
 }
 
+#ifdef HVLA_BENCH_HOOKS
+// libhvla_bench.so only: shader-clock stamps of workgroup 0 at the phase boundaries (tools/ctx_phase_times.py)
+__device__ unsigned long long g_ctx_stamps[64];
+#define CTX_STAMP(i)                                                                    \
+  do {                                                                                  \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 64) g_ctx_stamps[(i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define CTX_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(CTX_THREADS) void ctx_encoder_kernel(CtxParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;
@@ -91,122 +185,161 @@ __global__ __launch_bounds__(CTX_THREADS) void ctx_encoder_kernel(CtxParams p) {
   float* x = reinterpret_cast<float*>(smem);            // [S][ldx] residual stream
   float* h = x + S * ldx;                                // [S][ldx] LN output / attention output
   float* big = h + S * ldx;                              // [S][max(ldq, ldf)] qkv or mlp hidden
+  CTX_STAMP(0);
   // ---- token projection: x[s] = tok[s] @ Wt + bt + pos_t[s]     (hypernetwork.py:112-115)
   {
     const float* tok = p.tok + (size_t)b * T * p.lang_dim;
-    // stage the token rows in K-chunks of `kc` through `big`
-    const int kc = 128, ldt = kc + 4;
-    const int nrg = CTX_THREADS / C, rg = (T + nrg - 1) / nrg;       // C divides CTX_THREADS (128, 64, 32)
-    float acc[CTX_RG];
-    const int n = threadIdx.x % C, g0 = (threadIdx.x / C) * rg;
-    const bool active = threadIdx.x < nrg * C;
-#pragma unroll
-    for (int r = 0; r < CTX_RG; ++r) acc[r] = 0.f;
+    // the token rows go through `big` in K-chunks (row stride == 4 mod 64 words); every wave keeps its tile's sums over the chunks
+    const int kc = T * 388 <= p.big_elems ? 384 : 128, ldt = kc + 4;
+    const int wave = threadIdx.x >> 6, ntc = C >> 4;
+    const bool split = ntc * 2 <= CTX_WAVES && (p.lang_dim & 7) == 0;
+    const int tc = wave % ntc, kh = split ? (wave < 2 * ntc ? wave / ntc : -1) : (wave < ntc ? 0 : -1);
+    Acc3 acc;
+    acc3_zero(acc);
     for (int k0 = 0; k0 < p.lang_dim; k0 += kc) {
       const int kw = min(kc, p.lang_dim - k0);
       __syncthreads();
-      for (int i = threadIdx.x; i < T * kc; i += CTX_THREADS) {
-        const int s = i / kc, k = i % kc;
-        big[s * ldt + k] = k < kw ? tok[(size_t)s * p.lang_dim + k0 + k] : 0.f;
+      for (int i = threadIdx.x; i < T * (kw >> 2); i += CTX_THREADS) {
+        const int s = i / (kw >> 2), k = (i % (kw >> 2)) * 4;
+        *reinterpret_cast<f32x4*>(big + s * ldt + k) = *reinterpret_cast<const f32x4*>(tok + (size_t)s * p.lang_dim + k0 + k);
       }
       __syncthreads();
-      if (active) {
-        for (int k = 0; k < kw; k += 4) {
-          const float* W = p.w_tok + (size_t)(k0 + k) * C + n;
-          const float w0 = W[0], w1 = W[C], w2 = W[2 * C], w3 = W[3 * C];
-#pragma unroll
-          for (int r = 0; r < CTX_RG; ++r) {
-            if (r < rg) {                                            // uniform
-              int row = g0 + r;
-              row = row < T ? row : T - 1;
-              const f32x4 xv = *reinterpret_cast<const f32x4*>(big + row * ldt + k);
-              acc[r] = fmaf(xv[0], w0, fmaf(xv[1], w1, fmaf(xv[2], w2, fmaf(xv[3], w3, acc[r]))));
-            }
-          }
-        }
-      }
+      const int klen = split ? kw >> 1 : kw;
+      if (kh >= 0) mfma_cols(big, ldt, T, kh * klen, p.w_tok + (size_t)(k0 + kh * klen) * C, C, tc, klen, acc);
     }
-    if (active) {
-#pragma unroll
-      for (int r = 0; r < CTX_RG; ++r) {
-        const int row = g0 + r;
-        if (r < rg && row < T) x[row * ldx + n] = acc[r] + p.b_tok[n] + p.pos_tok[row * C + n];
-      }
-    }
+    auto put = [&](int row, int n, float v) { x[row * ldx + n] = v + p.b_tok[n] + p.pos_tok[row * C + n]; };
+    if (split) acc3_combine(acc, T, tc, kh, h, ldx, put);
+    else if (kh == 0) acc3_rows(acc, T, tc, put);
     __syncthreads();
-    // ---- initial-image CLS projection (hypernetwork.py:118-128) and layer token (:144-145)
+    CTX_STAMP(1);
+    // ---- initial-image CLS projection (hypernetwork.py:118-128) and layer token (:144-145): the E products of a column are
+    // summed in CTX_THREADS / C parts, then the parts in order
     const float* cls = p.cls + (size_t)b * p.E;
+    float* parts = big + p.E;
     for (int i = threadIdx.x; i < p.E; i += CTX_THREADS) big[i] = cls[i];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += CTX_THREADS) {
+    {
+      const int np = CTX_THREADS / C, kper = (p.E + np - 1) / np;
+      const int c = threadIdx.x % C, pi = threadIdx.x / C;
+      const int kb = pi * kper, ke = min(p.E, kb + kper);
       float a = 0.f;
-      for (int k = 0; k < p.E; ++k) a = fmaf(big[k], p.w_img[(size_t)k * C + c], a);
-      x[T * ldx + c] = a + p.b_img[c] + p.pos_img[c];
-      x[(T + 1) * ldx + c] = p.pos_layer[c];
+#pragma unroll 8
+      for (int k = kb; k < ke; ++k) a = fmaf(big[k], p.w_img[(size_t)k * C + c], a);
+      parts[pi * C + c] = a;
+      __syncthreads();
+      if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int i = 0; i < np; ++i) t += parts[i * C + c];
+        x[T * ldx + c] = t + p.b_img[c] + p.pos_img[c];
+        x[(T + 1) * ldx + c] = p.pos_layer[c];
+      }
     }
     __syncthreads();
   }
-  const int64_t* am = p.attn_mask + (size_t)b * T;
+  CTX_STAMP(2);
+  int* kmask = reinterpret_cast<int*>(big + p.big_elems);          // [T] language-token mask (read in the first layer after several barriers)
+  for (int k = threadIdx.x; k < T; k += CTX_THREADS) kmask[k] = p.attn_mask[(size_t)b * T + k] != 0;
   // ---- context Transformer (transformer.py:127-262)
   for (int l = 0; l < p.layers; ++l) {
     const CtxLayer& w = p.layer[l];
     ln_rows(x, h, ldx, S, C, w.ln0_s, w.ln0_b);
     __syncthreads();
+    CTX_STAMP(3 + 7 * l);
     // q | k | v = h @ W{q,k,v} + b    (flax DenseGeneral kernel [C, H, hd] == [C, C] row-major)
-    for (int which = 0; which < 3; ++which) {
+    for (int task = threadIdx.x >> 6; task < 3 * (C >> 4); task += CTX_WAVES) {     // 24 column tiles over 16 waves: 6 per SIMD
+      const int which = task / (C >> 4), tc = task % (C >> 4);
       const float* W = which == 0 ? w.wq : which == 1 ? w.wk : w.wv;
       const float* B = which == 0 ? w.bq : which == 1 ? w.bk : w.bv;
       const float sc = which == 0 ? rsqrtf((float)hc) : 1.f;     // query pre-scaling
-      dense_rows(h, ldx, S, C, W, C, [&](int s, int n, float v) { big[s * ldq + which * C + n] = (v + B[n]) * sc; });
+      Acc3 acc;
+      acc3_zero(acc);
+      const float bn = B[tc * 16 + (lane_here() & 15)];
+      mfma_cols(h, ldx, S, 0, W, C, tc, C, acc);
+      acc3_rows(acc, S, tc, [&](int s, int n, float v) { big[s * ldq + which * C + n] = (v + bn) * sc; });
     }
     __syncthreads();
-    // attention: one thread per (head, query)
-    for (int it = threadIdx.x; it < Hc * S; it += CTX_THREADS) {
-      const int hh = it / S, q = it % S;
-      const float* qp = big + q * ldq + hh * hc;
-      float sc[2 * CTX_RG];
-      float mx = -3.4028234663852886e38f;
+    CTX_STAMP(4 + 7 * l);
+    // attention on the matrix cores, transposed: one wave per (head, 16-query tile).  S^T = K Q^T leaves lane (query = l & 15,
+    // kq = l >> 4) with the logits of keys 16 kt + 4 kq + r of its query -- exactly the B operand P^T[key slot][query] that
+    // O^T = V^T P^T wants when MFMA k slot kq of step (kt, r) is read as key 16 kt + 4 kq + r, so the probabilities never leave
+    // their registers; the softmax reduces in-lane and over the four lanes of a query (xor 16, 32).
+    {
+      const int nqt = (S + 15) >> 4;
+      for (int task = threadIdx.x >> 6; task < Hc * nqt; task += CTX_WAVES) {
+        const int hh = task / nqt, qt = task % nqt;
+        const int lane = lane_here(), j = lane & 15, kq = lane >> 4;
+        const int q = qt * 16 + j, qr = q < S ? q : S - 1;
+        const float* qp = big + qr * ldq + hh * hc + kq;
+        f32x4 sc[3];
 #pragma unroll
-      for (int k = 0; k < 2 * CTX_RG; ++k) {
-        float s = -3.4028234663852886e38f;      // finfo(float32).min for masked logits
-        if (k < S) {
-          const bool keep = k < T ? (am[k] != 0) : (k == T ? true : (q == T + 1));
-          if (keep) {
-            const float* kp = big + k * ldq + C + hh * hc;
-            float a = 0.f;
-            for (int d = 0; d < hc; ++d) a = fmaf(qp[d], kp[d], a);
-            s = a;
+        for (int kt = 0; kt < 3; ++kt) {
+          sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (kt < nqt) {
+            const int kr = kt * 16 + j < S ? kt * 16 + j : S - 1;
+            const float* kp = big + kr * ldq + C + hh * hc + kq;
+            for (int d = 0; d < hc; d += 4) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[d], qp[d], sc[kt], 0, 0, 0);
           }
-          mx = fmaxf(mx, s);
         }
-        sc[k] = s;
-      }
-      float den = 0.f;
+        float mx = -3.4028234663852886e38f;        // finfo(float32).min stands in for a masked logit (transformer.py)
 #pragma unroll
-      for (int k = 0; k < 2 * CTX_RG; ++k) {
-        const float e = k < S ? __expf(sc[k] - mx) : 0.f;
-        sc[k] = e;
-        den += e;
-      }
-      const float inv = 1.f / den;
-      for (int d = 0; d < hc; ++d) {
-        float a = 0.f;
+        for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-        for (int k = 0; k < 2 * CTX_RG; ++k)
-          if (k < S) a = fmaf(sc[k], big[k * ldq + 2 * C + hh * hc + d], a);
-        h[q * ldx + hh * hc + d] = a * inv;
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * kq + r;
+            const bool keep = key < S && (key < T ? kmask[key] != 0 : (key == T ? true : q == T + 1));
+            sc[kt][r] = keep ? sc[kt][r] : -3.4028234663852886e38f;
+            mx = fmaxf(mx, sc[kt][r]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float den = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * kq + r;
+            const float e = key < S ? __expf(sc[kt][r] - mx) : 0.f;     // a masked key of the sequence gives exp(min - mx) = 0
+            sc[kt][r] = e;
+            den += e;
+          }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        const float inv = 1.f / den;
+        for (int dt = 0; dt * 16 < hc; ++dt) {
+          const int dd = dt * 16 + j < hc ? dt * 16 + j : hc - 1;
+          const float* vp = big + 2 * C + hh * hc + dd;
+          f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kt * 16 + r < S) {                 // uniform: the step's smallest key (kq = 0)
+                const int key = kt * 16 + 4 * kq + r < S ? kt * 16 + 4 * kq + r : S - 1;     // past the end: probability 0 times a real row
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[key * ldq], sc[kt][r], o, 0, 0, 0);
+              }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = dt * 16 + 4 * kq + r;
+            if (d < hc && q < S) h[q * ldx + hh * hc + d] = o[r] * inv;
+          }
+        }
       }
     }
     __syncthreads();
+    CTX_STAMP(5 + 7 * l);
     // out projection + residual   (kernel [H, hd, C] == [C, C] row-major)
-    dense_rows(h, ldx, S, C, w.wo, C, [&](int s, int n, float v) { x[s * ldx + n] += v + w.bo[n]; });
+    dense_mfma(h, ldx, S, C, w.wo, C, w.bo, big, ldq, [&](int s, int n, float v) { x[s * ldx + n] += v; });     // q|k|v are dead: `big` takes the partial sums
     __syncthreads();
+    CTX_STAMP(6 + 7 * l);
     ln_rows(x, h, ldx, S, C, w.ln1_s, w.ln1_b);
     __syncthreads();
-    dense_rows(h, ldx, S, C, w.w1, F, [&](int s, int n, float v) { big[s * ldf + n] = gelu_tanh(v + w.b1[n]); });
+    CTX_STAMP(7 + 7 * l);
+    dense_mfma(h, ldx, S, C, w.w1, F, w.b1, nullptr, 0, [&](int s, int n, float v) { big[s * ldf + n] = gelu_tanh(v); });
     __syncthreads();
-    dense_rows(big, ldf, S, F, w.w2, C, [&](int s, int n, float v) { x[s * ldx + n] += v + w.b2[n]; });
+    CTX_STAMP(8 + 7 * l);
+    dense_mfma(big, ldf, S, F, w.w2, C, w.b2, h, ldx, [&](int s, int n, float v) { x[s * ldx + n] += v; });      // h (LN output) is dead
     __syncthreads();
+    CTX_STAMP(9 + 7 * l);
   }
   // ---- encoder_norm on the layer-token row, scale, publish (hypernetwork.py:188-192)
   if (threadIdx.x < 64) {
@@ -351,6 +484,10 @@ __global__ void export_theta_kernel(const __bf16* wh, const __bf16* wl, const fl
   }
 }
 
+#ifdef HVLA_BENCH_HOOKS
+hipError_t debug_ctx_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ctx_stamps), sizeof(unsigned long long) * 64); }
+#endif
+
 // ---- launchers -----------------------------------------------------------------------------------
 hipError_t launch_ctx_encoder(const CtxParams& p, int B, hipStream_t st) {
   const int S = p.T + 2;
@@ -358,8 +495,10 @@ hipError_t launch_ctx_encoder(const CtxParams& p, int B, hipStream_t st) {
   int bigld = ldq > ldf ? ldq : ldf;
   if (bigld < 132) bigld = 132;
   size_t big_elems = (size_t)S * bigld;
-  if (big_elems < (size_t)p.E) big_elems = p.E;
-  const size_t smem = ((size_t)2 * S * ldx + big_elems) * sizeof(float);
+  if (big_elems < (size_t)p.E + CTX_THREADS) big_elems = (size_t)p.E + CTX_THREADS;
+  CtxParams q = p;
+  q.big_elems = (int)big_elems;
+  const size_t smem = ((size_t)2 * S * ldx + big_elems + 64) * sizeof(float);      // + the key mask
   static bool attr_done[64] = {};                              // per device: the attribute belongs to the device's code object
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -371,7 +510,7 @@ hipError_t launch_ctx_encoder(const CtxParams& p, int B, hipStream_t st) {
     attr_done[dev] = true;
   }
   if (smem > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ctx_encoder_kernel, dim3(B), dim3(CTX_THREADS), smem, st, p);
+  hipLaunchKernelGGL(ctx_encoder_kernel, dim3(B), dim3(CTX_THREADS), smem, st, q);
   return hipGetLastError();
 }
 

@@ -16,6 +16,7 @@ struct CtxLayer {
 constexpr int CTX_MAX_LAYERS = 8;
 struct CtxParams {
   int T, C, F, heads, layers, lang_dim, E, scale_context;
+  int big_elems;             // floats in the kernel's third LDS buffer (set by launch_ctx_encoder)
   const float* tok;          // [B, T, lang_dim]
   const int64_t* attn_mask;  // [B, T]
   const float* cls;          // [B, E]
@@ -92,6 +93,7 @@ hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const E
 #ifdef HVLA_BENCH_HOOKS
 hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st);
+hipError_t debug_ctx_stamps(unsigned long long* out);   // [64] shader-clock stamps of the last context-encoder launch
 hipError_t debug_attention_stamps(const void* qkv, void* o, void* omean, int B, int S, int E, int H, int wg, unsigned long long* stamps,
                                   hipStream_t st);
 #endif
