@@ -1355,26 +1355,48 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 // the two): half wm = rows [wm P/2, +P/2) of the image; inside a half, quad q (rows 4q..4q+3) goes to partial q & 3, each
 // partial adds its values in ascending row order IN THE 16-BIT TYPE, the half is (p0 + p1) + (p2 + p3) in f32, and each
 // half's mean (half / (P / 2), rounded to the operand type) is one row of the table [image][half][K].
+// Only small batches come here (a large batch gets the sums from the GELU epilogue), so the launch is one latency chain and is
+// laid out for that: the eight independent partial sums of a column (2 halves x 4 partials) go to eight 32-lane groups, a lane
+// takes eight adjacent columns with 16-byte loads and has 16 rows in flight (23 -> 4 us at B = 1: twelve workgroups walking
+// 256 rows with four 2-byte loads in flight each).
 template <typename T>
 __global__ __launch_bounds__(256) void colmean_kernel(const T* __restrict__ a, T* __restrict__ abar, int S, int P, int K) {
-  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= K) return;
-  const T* base = a + ((size_t)b * S + 1) * K + n;
-  const int half = P / 2;
-  float hs[2];
-  for (int wm = 0; wm < 2; ++wm) {
-    T p[4] = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};       // accumulated in the operand type, as the GELU epilogue does
-    for (int q = 0; q < half / 4; ++q) {
-      T v[4];
+  typedef T T8 __attribute__((ext_vector_type(8)));
+  __shared__ float part[8][256];
+  const int b = blockIdx.y, chain = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+  const int wm = chain >> 2, pq = chain & 3;
+  const int n0 = blockIdx.x * 256 + l32 * 8;
+  const int half = P / 2, nq = half / 4;
+  T8 p;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = base[(size_t)(wm * half + 4 * q + r) * K];
+  for (int i = 0; i < 8; ++i) p[i] = (T)0.f;                 // accumulated in the operand type, as the GELU epilogue does
+  if (n0 < K) {
+    const T* base = a + ((size_t)b * S + 1 + wm * half) * K + n0;
+    for (int q = pq; q < nq; q += 16) {                       // quads q, q + 4, q + 8, q + 12 of this partial: ascending rows
+      T8 v[4][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[q & 3] = p[q & 3] + v[r];
+      for (int u = 0; u < 4; ++u)
+        if (q + 4 * u < nq) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[u][r] = *reinterpret_cast<const T8*>(base + (size_t)(4 * (q + 4 * u) + r) * K);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q + 4 * u < nq) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p = p + v[u][r];
+        }
     }
-    hs[wm] = ((float)p[0] + (float)p[1]) + ((float)p[2] + (float)p[3]);
   }
-  abar[((size_t)b * 2 + 0) * K + n] = (T)(hs[0] * (1.f / (float)half));       // [image][half][K], as the GELU epilogue writes it
-  abar[((size_t)b * 2 + 1) * K + n] = (T)(hs[1] * (1.f / (float)half));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[chain][l32 * 8 + i] = (float)p[i];
+  __syncthreads();
+  const int t = threadIdx.x, n = blockIdx.x * 256 + t;
+  if (n >= K) return;
+  const float h0 = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  const float h1 = (part[4][t] + part[5][t]) + (part[6][t] + part[7][t]);
+  abar[((size_t)b * 2 + 0) * K + n] = (T)(h0 * (1.f / (float)half));       // [image][half][K], as the GELU epilogue writes it
+  abar[((size_t)b * 2 + 1) * K + n] = (T)(h1 * (1.f / (float)half));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1527,6 +1549,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       float* partial = comp ? reinterpret_cast<float*>(ws.g) : nullptr;      // ws.g is free at both LayerNorms: [B][2][LNW][E] f32
       hipLaunchKernelGGL((layernorm_split_kernel<Op>), dim3(LNW, B), dim3(LNW * 64), (size_t)((S + LNW - 1) / LNW) * E * sizeof(float),
                          st, ws.x, reinterpret_cast<T*>(ws.h), sc, bi, partial, S, E, hsplit);
+      // (one launch with the image's last workgroup to arrive -- ticket by atomicAdd behind a __threadfence -- adding the
+      // partials was tried: 14.0 us against 5.2 + 4.7 for the two launches, profiles/r3_experiments_not_kept.txt)
       if (comp) hipLaunchKernelGGL((layernorm_mean_kernel<Op>), dim3(2 * B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), S, E, hsplit);
       return;
     }

@@ -382,8 +382,11 @@ template <int KS>
 __global__ __launch_bounds__(256) void weightgen_kernel(WeightGenParams p) {
   __shared__ __attribute__((aligned(16))) __bf16 stage[2][32][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + wave;
-  const bool via_lds = blockIdx.x * 4 + 3 < p.ntiles && (blockIdx.x * 4 + 4) * 32 <= p.Gm;     // workgroup-uniform
+  // (2 / 4 / 8 workgroups per group of four position tiles, each taking every 2nd / 4th / 8th episode tile, were tried to even
+  // out the last round over the CUs: 1.10 -> 1.11 / 1.17 / 1.27 ms per create_tasks at B = 256, the W_cat fragments read again)
+  const int wg = blockIdx.x;
+  const int tile = wg * 4 + wave;
+  const bool via_lds = wg * 4 + 3 < p.ntiles && (wg * 4 + 4) * 32 <= p.Gm;     // workgroup-uniform
   if (tile >= p.ntiles) return;                  // (only in a workgroup that is not via_lds: no barrier is skipped)
   const int col = lane & 31, half = lane >> 5;
   bf16x8 ah[KS], al[KS];
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256) void weightgen_kernel(WeightGenParams p) {
       bf16x8* sl = reinterpret_cast<bf16x8*>(&stage[1][col][wave * 32 + half * 16]);
       sh[0] = h0, sh[1] = h1, sl[0] = l0, sl[1] = l1;
       __syncthreads();
-      const size_t gpos = (size_t)blockIdx.x * 128 + (lane & 15) * 8;          // 16 lanes x 16 B = one episode's 256-byte run
+      const size_t gpos = (size_t)wg * 128 + (lane & 15) * 8;          // 16 lanes x 16 B = one episode's 256-byte run
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int row = wave * 8 + u * 4 + (lane >> 4);
