@@ -476,19 +476,25 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     boff = (uint32_t)mr * (uint32_t)g.K + sch;
   }
   const int KT = g.K / 64;
-  auto issue = [&](int kt) {
-    char* base = smem + (kt % SNSC) * SSTC + wave * 1024;
+  // LDS-DMA issued by hand (SGPR base + 32-bit lane offset, M0 saved / written / restored inside the statement: see
+  // gemm256p_kernel): the builtin is a FLAT-encoded instruction for the compiler's wait-count model, and with one of those
+  // pending it waits for EVERY LDS read in flight (lgkmcnt(0)) before an MFMA that needs the older fragment set only.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto dma = [&](const T* sb, uint32_t elem_off, uint32_t dst) {
+    const uint32_t vo = elem_off * (uint32_t)sizeof(T);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(sb), "s"(dst));
+  };
+  auto issue_at = [&](int kt, int slot) {           // K-tile kt into the stage of tile `slot`
+    const uint32_t base = lds0 + (uint32_t)((slot % SNSC) * SSTC + wave * 1024);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoff[j] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(base + j * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + woff[j] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(base + 8192 + j * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dW + woff[j] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(base + 16384 + j * 4096), 16, 0, 0);
+      dma(A, aoff[j] + kt * 64, base + j * 4096);
+      dma(W, woff[j] + kt * 64, base + 8192 + j * 4096);
+      dma(dW, woff[j] + kt * 64, base + 16384 + j * 4096);
     }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(AB + boff + kt * 64),
-                                     (__attribute__((address_space(3))) void*)(base + 24576), 16, 0, 0);
+    dma(AB, boff + kt * 64, base + 24576);
   };
   f32x4 acc[4][1], acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -498,44 +504,69 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
   const int a_off = (wave * 16 + fr) * 128, w_off = 8192 + fr * 128;
   const int d_off = 16384 + (wave * 16 + fr) * 128, b_off = 24576 + fr * 128;
 #pragma unroll
-  for (int s = 0; s < SNSC - 1; ++s)
-    if (s < KT) issue(s);
-  for (int kt = 0; kt < KT; ++kt) {
-    const int issued = kt + SNSC - 1 < KT ? kt + SNSC - 1 : KT;
-    switch (issued - kt - 1) {                       // K-tiles issued after tile kt may stay in flight (7 pieces each)
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");                   // (see gemm64_body)
-    __builtin_amdgcn_sched_barrier(0);
-    const char* lb = smem + (kt % SNSC) * SSTC;
+  for (int s = 0; s < SNSC - 1; ++s) issue_at(s < KT ? s : KT - 1, s);
+  // One workgroup per CU (140 KB of stages) and at B = 1 only 60-240 workgroups in all: nothing but this workgroup's own waves
+  // can hide its LDS round trip, so the fragments of K-tile kt + 1 are read while the MFMAs of tile kt run (two register
+  // sets).  The MFMA chain of every accumulator is the one it always was: same bits.
+  struct Frags {
     X8 fa[2], fw[4][2], fb[2], fd[2];
-    fa[0] = *reinterpret_cast<const X8*>(lb + a_off + sw0);
-    fa[1] = *reinterpret_cast<const X8*>(lb + a_off + sw1);
+  };
+  auto read_frags = [&](int t, Frags& f) {
+    const char* lb = smem + (t % SNSC) * SSTC;
+    f.fa[0] = *reinterpret_cast<const X8*>(lb + a_off + sw0);
+    f.fa[1] = *reinterpret_cast<const X8*>(lb + a_off + sw1);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      fw[nt][0] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw0);
-      fw[nt][1] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw1);
+      f.fw[nt][0] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw0);
+      f.fw[nt][1] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw1);
     }
-    fb[0] = *reinterpret_cast<const X8*>(lb + b_off + sw0);
-    fb[1] = *reinterpret_cast<const X8*>(lb + b_off + sw1);
-    fd[0] = *reinterpret_cast<const X8*>(lb + d_off + sw0);
-    fd[1] = *reinterpret_cast<const X8*>(lb + d_off + sw1);
+    f.fb[0] = *reinterpret_cast<const X8*>(lb + b_off + sw0);
+    f.fb[1] = *reinterpret_cast<const X8*>(lb + b_off + sw1);
+    f.fd[0] = *reinterpret_cast<const X8*>(lb + d_off + sw0);
+    f.fd[1] = *reinterpret_cast<const X8*>(lb + d_off + sw1);
+  };
+  // No branch inside a step (behind a join the compiler's wait for `cur` becomes lgkmcnt(0), i.e. also waits for `nxt`): past
+  // the end the reads fetch a stale stage and the DMA stages the last K-tile once more, both unused -- and every step has the
+  // same SNSC - 3 younger tiles in flight when it waits for tile kt + 1, so that wait is the constant vmcnt(14).
+  static_assert(SNSC == 5, "the wait constants below are for five stages of seven pieces");
+  auto step = [&](int kt, const Frags& cur, Frags& nxt) {
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + SNSC - 1 < KT) issue(kt + SNSC - 1);    // into the stage of tile kt - 1; issued while the fragment reads are in flight
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // tile kt + 1 is in LDS for every wave, and every wave holds tile kt - 1's fragments (its MFMAs needed them)
+    asm volatile("" ::: "memory");                   // (see gemm64_body)
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(kt + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_at(kt + SNSC - 1 < KT ? kt + SNSC - 1 : KT - 1, kt + SNSC - 1);    // into the stage of tile kt - 1
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt][0] = Op::mma16(fa[kk], fw[nt][kk], acc[nt][0]);
-      acc2 = Op::mma16(fb[kk], fd[kk], acc2);
+      for (int nt = 0; nt < 4; ++nt) acc[nt][0] = Op::mma16(cur.fa[kk], cur.fw[nt][kk], acc[nt][0]);
+      acc2 = Op::mma16(cur.fb[kk], cur.fd[kk], acc2);
     }
+  };
+  Frags f0, f1;
+  asm volatile("s_waitcnt vmcnt(21)" ::: "memory");  // tile 0 (the prologue issued four tiles, past the end the last one again)
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(0, f0);
+  // (behind the loop header's join the compiler waits for every LDS read in flight before the first MFMA, i.e. step kt of
+  // each group of four does not overlap its reads; the other three do)
+  int kt = 0;
+  for (; kt + 4 <= KT; kt += 4) {
+    step(kt, f0, f1);
+    step(kt + 1, f1, f0);
+    step(kt + 2, f0, f1);
+    step(kt + 3, f1, f0);
   }
+  for (; kt < KT; ++kt) {
+    step(kt, f0, f1);
+    f0 = f1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA past the end still writes into the stages: the table below takes their place
   // acc2[r] = (mean row 2 img0 + 4 fq + r) . dW[:, n0 + 4 fr + wave] x 4096  ->  table[(image - img0) * 2 + half][4 fr + wave]
   __builtin_amdgcn_s_barrier();                      // every wave is done with the last stage: its space takes the table
   float* table = reinterpret_cast<float*>(smem);
