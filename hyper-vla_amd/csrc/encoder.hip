@@ -581,6 +581,160 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
   else gemm_epilogue_rows_impl<Op, EPI, 1, false, true>(acc, g, m0 + wave * 16, n0, fr, fq, nullptr, nullptr, nullptr, lt, img0);
 }
 
+// gemm64c32_kernel -- gemm64c_kernel<EPI_RES> on 64 x 32 tiles, for the two residual GEMMs of a layer (out-projection, fc2:
+// N = E) when the 64 x 64 grid would fill less than half of the chip (60 workgroups at B = 1).  The K loop of that kernel
+// runs at what one CU's vector memory pipe moves (28 KB per K-tile); this one stages 20 KB per K-tile (A 8 | W 4 | dW 4 |
+// mean rows 4) on twice as many CUs, seven stages deep.  W rows are staged so that LDS row 16 nt + c holds global column
+// 2 c + nt: lane (fr, fq) owns the two adjacent columns n0 + 2 fr + {0, 1} of its four rows.  Same operands, same MFMA,
+// same k order per accumulator, the same epilogue arithmetic (acc + bias row, then fma with the layer scale into x) as
+// gemm_epilogue_rows_impl<EPI_RES>: the same bits as every other path (the batch-invariance tests cross them).
+constexpr int SNS32 = 7, SST32 = 20480;
+template <typename Op>
+__global__ __launch_bounds__(256) void gemm64c32_kernel(GemmArgs g) {
+  using T = typename Op::elem;
+  using X8 = typename Op::x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbm = (g.M + SBM - 1) / SBM;
+  const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
+  const int m0 = bm * SBM, n0 = bn * 32;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const T* dW = reinterpret_cast<const T*>(g.dW2);
+  const T* AB = reinterpret_cast<const T*>(g.abar2);
+  const int img0 = (g.row0 + m0 * g.row_step) / g.S;
+  const int sch = ((lane & 7) ^ (lane >> 3)) * 8;
+  uint32_t aoff[2], woff, boff;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int m = m0 + 32 * j + 8 * wave + (lane >> 3);
+    m = m < g.M ? m : g.M - 1;
+    aoff[j] = (uint32_t)(g.row0 + m * g.row_step) * (uint32_t)g.K + sch;
+  }
+  {
+    const int rl = 8 * wave + (lane >> 3);                    // LDS row of the W / dW stage -> global column 2 (rl & 15) + (rl >> 4)
+    woff = (uint32_t)(n0 + 2 * (rl & 15) + (rl >> 4)) * (uint32_t)g.K + sch;
+    int mr = img0 * 2 + rl;
+    mr = mr < g.M2 ? mr : g.M2 - 1;
+    boff = (uint32_t)mr * (uint32_t)g.K + sch;
+  }
+  const int KT = g.K / 64;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto dma = [&](const T* sb, uint32_t elem_off, uint32_t dst) {
+    const uint32_t vo = elem_off * (uint32_t)sizeof(T);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(sb), "s"(dst));
+  };
+  auto issue_at = [&](int kt, int slot) {           // five pieces per wave and K-tile
+    const uint32_t base = lds0 + (uint32_t)((slot % SNS32) * SST32 + wave * 1024);
+    dma(A, aoff[0] + kt * 64, base);
+    dma(A, aoff[1] + kt * 64, base + 4096);
+    dma(W, woff + kt * 64, base + 8192);
+    dma(dW, woff + kt * 64, base + 12288);
+    dma(AB, boff + kt * 64, base + 16384);
+  };
+  f32x4 acc[2], acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc[0] = acc2;
+  acc[1] = acc2;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw0 = (fq ^ (fr & 7)) << 4, sw1 = ((fq + 4) ^ (fr & 7)) << 4;
+  const int a_off = (wave * 16 + fr) * 128, w_off = 8192 + fr * 128;
+  const int d_off = 12288 + ((wave & 1) * 16 + fr) * 128, b_off = 16384 + fr * 128;      // waves 2, 3 repeat n-tiles 0, 1 and drop the result
+#pragma unroll
+  for (int s = 0; s < SNS32 - 1; ++s) issue_at(s < KT ? s : KT - 1, s);
+  struct Frags {
+    X8 fa[2], fw[2][2], fb[2], fd[2];
+  };
+  auto read_frags = [&](int t, Frags& f) {
+    const char* lb = smem + (t % SNS32) * SST32;
+    f.fa[0] = *reinterpret_cast<const X8*>(lb + a_off + sw0);
+    f.fa[1] = *reinterpret_cast<const X8*>(lb + a_off + sw1);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f.fw[nt][0] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw0);
+      f.fw[nt][1] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw1);
+    }
+    f.fb[0] = *reinterpret_cast<const X8*>(lb + b_off + sw0);
+    f.fb[1] = *reinterpret_cast<const X8*>(lb + b_off + sw1);
+    f.fd[0] = *reinterpret_cast<const X8*>(lb + d_off + sw0);
+    f.fd[1] = *reinterpret_cast<const X8*>(lb + d_off + sw1);
+  };
+  // as in gemm64c_kernel: branch-free steps, constant waits (SNS32 - 3 = 4 younger tiles of 5 pieces in flight behind tile kt + 1)
+  static_assert(SNS32 == 7, "the wait constants below are for seven stages of five pieces");
+  auto step = [&](int kt, const Frags& cur, Frags& nxt) {
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(kt + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_at(kt + SNS32 - 1 < KT ? kt + SNS32 - 1 : KT - 1, kt + SNS32 - 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      acc[0] = Op::mma16(cur.fa[kk], cur.fw[0][kk], acc[0]);
+      acc[1] = Op::mma16(cur.fa[kk], cur.fw[1][kk], acc[1]);
+      acc2 = Op::mma16(cur.fb[kk], cur.fd[kk], acc2);
+    }
+  };
+  Frags f0, f1;
+  asm volatile("s_waitcnt vmcnt(25)" ::: "memory");  // tile 0: five younger tiles in flight
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(0, f0);
+  int kt = 0;
+  for (; kt + 4 <= KT; kt += 4) {
+    step(kt, f0, f1);
+    step(kt + 1, f1, f0);
+    step(kt + 2, f0, f1);
+    step(kt + 3, f1, f0);
+  }
+  for (; kt < KT; ++kt) {
+    step(kt, f0, f1);
+    f0 = f1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // acc2[r] = (mean row 2 img0 + 4 fq + r) . dW[:, n0 + 2 fr + wave] x 4096 (waves 0, 1)  ->  table[(image - img0) * 2 + half][2 fr + wave]
+  __builtin_amdgcn_s_barrier();
+  float* table = reinterpret_cast<float*>(smem);
+  if (wave < 2) {
+    const f32x4 cv = corr_value(acc2, g.bias[n0 + 2 * fr + wave]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) table[(4 * fq + r) * 32 + 2 * fr + wave] = cv[r];
+  }
+  __syncthreads();
+  typedef float f32x2e __attribute__((ext_vector_type(2)));
+  const int n = n0 + 2 * fr;
+  const f32x2e l2 = *reinterpret_cast<const f32x2e*>(g.aux + n);
+  const f32x2e b2 = *reinterpret_cast<const f32x2e*>(g.bias + n);
+  f32x2e xin[4], brow[4];
+  uint32_t off[4];
+  bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                      // the four residual loads are requested together
+    const int m = m0 + wave * 16 + 4 * fq + r;
+    ok[r] = m < g.M;
+    const int grow = g.row0 + (ok[r] ? m : g.M - 1) * g.row_step;
+    off[r] = (uint32_t)grow * (uint32_t)g.N + (uint32_t)n;
+    xin[r] = *reinterpret_cast<const f32x2e*>(reinterpret_cast<const float*>(g.out) + off[r]);
+    const int img = grow / g.S, tok = grow - img * g.S, hf = tok >= g.hsplit ? 1 : 0;
+    brow[r] = tok ? *reinterpret_cast<const f32x2e*>(table + ((img - img0) * 2 + hf) * 32 + 2 * fr) : b2;      // CLS row: plain bias
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (!ok[r]) continue;
+    f32x2e x = xin[r];
+    x[0] = fmaf(acc[0][r] + brow[r][0], l2[0], x[0]);
+    x[1] = fmaf(acc[1][r] + brow[r][1], l2[1], x[1]);
+    *reinterpret_cast<f32x2e*>(reinterpret_cast<float*>(g.out) + off[r]) = x;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // gemm256p_kernel -- the production GEMM.  256x256x64 block tiles, 8 waves (2 along M x 4 along N, 128x64 each), operands
 // staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction).  The LDS
@@ -1497,7 +1651,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
     SETA((gemm64_kernel<Op, EPI_RES>)) SETA((gemm64_kernel<Op, EPI_CORR>))
     SETA((gemm64_kernel<Op, EPI_QKV, 4>)) SETA((gemm64_kernel<Op, EPI_GELU, 4>)) SETA((gemm64_kernel<Op, EPI_RES, 4>))
-    SETA((gemm64c_kernel<Op, EPI_QKV>)) SETA((gemm64c_kernel<Op, EPI_GELU>)) SETA((gemm64c_kernel<Op, EPI_RES>))
+    SETA((gemm64c_kernel<Op, EPI_QKV>)) SETA((gemm64c_kernel<Op, EPI_GELU>)) SETA((gemm64c_kernel<Op, EPI_RES>)) SETA((gemm64c32_kernel<Op>))
 #undef SETA
     di.attr[opi] = true;
   }
@@ -1555,7 +1709,15 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
         a.abar2 = ws.abar; a.dW2 = dW; a.M2 = 2 * B;
         pf.end(CAT_COMP, st);
         pf.begin(cat, st);
-        hipLaunchKernelGGL((gemm64c_kernel<Op, EPI>), dim3(((M + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNSC * SSTC, st, a);
+        const int nb64 = ((M + SBM - 1) / SBM) * (N / SBN);
+        if constexpr (EPI == EPI_RES) {
+          if (2 * nb64 <= ncu) {                     // less than half of the chip: 64 x 32 tiles on twice as many CUs
+            hipLaunchKernelGGL((gemm64c32_kernel<Op>), dim3(2 * nb64), dim3(256), SNS32 * SST32, st, a);
+            pf.end(cat, st);
+            return false;
+          }
+        }
+        hipLaunchKernelGGL((gemm64c_kernel<Op, EPI>), dim3(nb64), dim3(256), SNSC * SSTC, st, a);
         pf.end(cat, st);
         return false;
       }
