@@ -378,17 +378,43 @@ __global__ __launch_bounds__(CTX_THREADS) void ctx_encoder_kernel(CtxParams p) {
 // tiles all lie in the matrix region therefore go through LDS: the four waves park their [32 episodes x 32 positions] hi and
 // lo tiles side by side ([plane][episode][128 positions] = 16 KB), and every wave then writes eight episode rows as 256-byte
 // runs (16 lanes x 16 B per row).  The vector region (f32, 10 % of the bytes) and a ragged last workgroup keep the direct form.
+// Round 3: the B operand (the 32 episodes' ctx rows, hi and lo) no longer comes from global memory per wave and k-step -- 16
+// loads per wave and episode tile whose 64 lanes pick 16-byte pieces out of 32 different rows, four waves fetching the same
+// rows: that was most of what the CU's vector memory pipe did, and every iteration began with their round trip -- but through
+// LDS: the tile's 32 rows are contiguous in memory, so the workgroup stages them with KS / 2 LDS-DMA instructions per wave
+// (1 KB each, linear; the 16-byte chunk index XORed with the row on the SOURCE address so that the ds_read_b128 of 16 rows at
+// one k chunk spread over all banks), one tile ahead (double buffer), and the four waves read their fragments from there.
 template <int KS>
-__global__ __launch_bounds__(256) void weightgen_kernel(WeightGenParams p) {
+__global__ __launch_bounds__(256, 3) void weightgen_kernel(WeightGenParams p) {      // 48 KB of LDS: three workgroups per CU
+  constexpr int CH = 2 * KS;                       // 16-byte chunks per ctx row (C = 16 KS bf16)
+  constexpr int IPW = KS / 2 > 0 ? KS / 2 : 1;     // DMA instructions per wave and episode tile (2 planes x 32 rows x CH chunks / 64 lanes / 4 waves)
   __shared__ __attribute__((aligned(16))) __bf16 stage[2][32][128];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // (2 / 4 / 8 workgroups per group of four position tiles, each taking every 2nd / 4th / 8th episode tile, were tried to even
-  // out the last round over the CUs: 1.10 -> 1.11 / 1.17 / 1.27 ms per create_tasks at B = 256, the W_cat fragments read again)
+  __shared__ __attribute__((aligned(16))) __bf16 cbuf[2][2][32 * KS * 16];      // [buffer][hi / lo][row][chunk ^ row][8]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wg = blockIdx.x;
-  const int tile = wg * 4 + wave;
+  const bool active = wg * 4 + wave < p.ntiles;      // a ragged last workgroup: its spare waves still stage and go to the barriers
+  const int tile = active ? wg * 4 + wave : p.ntiles - 1;
   const bool via_lds = wg * 4 + 3 < p.ntiles && (wg * 4 + 4) * 32 <= p.Gm;     // workgroup-uniform
-  if (tile >= p.ntiles) return;                  // (only in a workgroup that is not via_lds: no barrier is skipped)
   const int col = lane & 31, half = lane >> 5;
+  const uint32_t lds_c = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&cbuf[0][0][0];
+  auto stage_ctx = [&](int b0, int buf) {
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const int j = wave * IPW + u;                  // instruction of the tile: plane j / KS, 1 KB piece j % KS
+      if (KS < 2 && j >= 2 * KS) break;
+      const int plane = j / KS, piece = j % KS;
+      const int pos = piece * 64 + lane;             // 16-byte position inside the plane's tile
+      const int r = pos / CH, c = pos % CH;
+      int b = b0 + r;
+      b = b < p.B ? b : p.B - 1;
+      const __bf16* src = (plane ? p.ctx_lo : p.ctx_hi) + (size_t)b * (KS * 16) + ((c ^ (r & (CH - 1))) * 8);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_c + (uint32_t)(((buf * 2 + plane) * 32 * KS * 16) * 2 + piece * 1024));
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst));
+    }
+  };
+  stage_ctx(0, 0);
   bf16x8 ah[KS], al[KS];
   {
     const bf16x8* Ah = reinterpret_cast<const bf16x8*>(p.wcat_hi) + ((size_t)tile * KS) * 64 + lane;
@@ -407,18 +433,27 @@ __global__ __launch_bounds__(256) void weightgen_kernel(WeightGenParams p) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(p.bcat + pos0 + r);
     bias[r] = v[0], bias[r + 1] = v[1], bias[r + 2] = v[2], bias[r + 3] = v[3];
   }
-  const int C = KS * 16;
-  for (int b0 = 0; b0 < p.B; b0 += 32) {
+  int it = 0;
+  for (int b0 = 0; b0 < p.B; b0 += 32, ++it) {
     const int b = b0 + col;
-    const int bc = b < p.B ? b : p.B - 1;
-    const bf16x8* Bh = reinterpret_cast<const bf16x8*>(p.ctx_hi + (size_t)bc * C + half * 8);
-    const bf16x8* Bl = reinterpret_cast<const bf16x8*>(p.ctx_lo + (size_t)bc * C + half * 8);
+    const bool more = b0 + 32 < p.B;
+    // the other buffer was last read two barriers ago (every iteration has at least one behind its MFMAs)
+    if (more) {
+      stage_ctx(b0 + 32, (it + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");     // this tile has landed (the A fragments and the last stores are older still)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                               // ... for every wave's share of it
+    const __bf16* ch = &cbuf[it & 1][0][0] + col * (KS * 16);
+    const __bf16* cl = &cbuf[it & 1][1][0] + col * (KS * 16);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bias[r];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 bh = Bh[ks * 2], bl = Bl[ks * 2];       // 16 bf16 per k-step = 2 x bf16x8
+      const int sw = ((ks * 2 + half) ^ (col & (CH - 1))) * 8;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ch + sw), bl = *reinterpret_cast<const bf16x8*>(cl + sw);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
@@ -449,25 +484,28 @@ __global__ __launch_bounds__(256) void weightgen_kernel(WeightGenParams p) {
           *reinterpret_cast<bf16x8*>(p.wl + (size_t)(b0 + row) * p.Gm + gpos) = vl;
         }
       }
-    } else if (b < p.B) {
-      if (pos0 < p.Gm) {
-        bf16x8 h0, h1, l0, l1;
+    } else {
+      if (active && b < p.B) {
+        if (pos0 < p.Gm) {
+          bf16x8 h0, h1, l0, l1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          __bf16 hi, lo;
-          split1(acc[j], hi, lo);
-          h0[j] = hi, l0[j] = lo;
-          split1(acc[8 + j], hi, lo);
-          h1[j] = hi, l1[j] = lo;
+          for (int j = 0; j < 8; ++j) {
+            __bf16 hi, lo;
+            split1(acc[j], hi, lo);
+            h0[j] = hi, l0[j] = lo;
+            split1(acc[8 + j], hi, lo);
+            h1[j] = hi, l1[j] = lo;
+          }
+          bf16x8* dh = reinterpret_cast<bf16x8*>(p.wh + (size_t)b * p.Gm + pos0);
+          bf16x8* dl = reinterpret_cast<bf16x8*>(p.wl + (size_t)b * p.Gm + pos0);
+          dh[0] = h0, dh[1] = h1, dl[0] = l0, dl[1] = l1;
+        } else {
+          f32x4* dv = reinterpret_cast<f32x4*>(p.vf + (size_t)b * p.Gv + (pos0 - p.Gm));
+#pragma unroll
+          for (int r = 0; r < 16; r += 4) dv[r >> 2] = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
         }
-        bf16x8* dh = reinterpret_cast<bf16x8*>(p.wh + (size_t)b * p.Gm + pos0);
-        bf16x8* dl = reinterpret_cast<bf16x8*>(p.wl + (size_t)b * p.Gm + pos0);
-        dh[0] = h0, dh[1] = h1, dl[0] = l0, dl[1] = l1;
-      } else {
-        f32x4* dv = reinterpret_cast<f32x4*>(p.vf + (size_t)b * p.Gv + (pos0 - p.Gm));
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) dv[r >> 2] = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
       }
+      __syncthreads();                             // (the via_lds form has its two: here one, so that nobody stages over a tile still being read)
     }
   }
 }
