@@ -471,11 +471,8 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     woff[j] = (uint32_t)(n0 + wperm(rl)) * (uint32_t)g.K + sch;
   }
   {
-    // the MFMA reads rows 0..15 of the mean-row tile (= (image, half) pairs from image img0 on; M2 = 2 B rows): wave w stages
-    // rows 4 w .. 4 w + 3 with the lower half of one DMA instruction (EXEC = 32 lanes inside the asm: no branch, the same number
-    // of pieces per wave and K-tile, half the bytes)
-    int mr = img0 * 2 + 4 * wave + ((lane & 31) >> 3);
-    mr = mr < g.M2 ? mr : g.M2 - 1;
+    int mr = img0 * 2 + 8 * wave + (lane >> 3);               // rows 0..31 of the mean-row tile = (image, half) pairs from image
+    mr = mr < g.M2 ? mr : g.M2 - 1;                           // img0 on (M2 = 2 B rows); the MFMA reads rows 0..15
     boff = (uint32_t)mr * (uint32_t)g.K + sch;
   }
   const int KT = g.K / 64;
@@ -489,13 +486,6 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(vo), "s"(sb), "s"(dst));
   };
-  auto dma_lo32 = [&](const T* sb, uint32_t elem_off, uint32_t dst) {      // lanes 0..31 only: 512 bytes
-    const uint32_t vo = elem_off * (uint32_t)sizeof(T);
-    uint32_t keep;
-    uint64_t keepx;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, %5\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep), "=&s"(keepx) : "v"(vo), "s"(sb), "s"(dst), "s"(0x00000000ffffffffull));
-  };
   auto issue_at = [&](int kt, int slot) {           // K-tile kt into the stage of tile `slot`
     const uint32_t base = lds0 + (uint32_t)((slot % SNSC) * SSTC + wave * 1024);
 #pragma unroll
@@ -504,7 +494,7 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
       dma(W, woff[j] + kt * 64, base + 8192 + j * 4096);
       dma(dW, woff[j] + kt * 64, base + 16384 + j * 4096);
     }
-    dma_lo32(AB, boff + kt * 64, base - wave * 512 + 24576);      // rows 4 wave .. + 3 at 512 bytes per wave
+    dma(AB, boff + kt * 64, base + 24576);
   };
   f32x4 acc[4][1], acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -625,7 +615,7 @@ __global__ __launch_bounds__(256) void gemm64c32_kernel(GemmArgs g) {
   {
     const int rl = 8 * wave + (lane >> 3);                    // LDS row of the W / dW stage -> global column 2 (rl & 15) + (rl >> 4)
     woff = (uint32_t)(n0 + 2 * (rl & 15) + (rl >> 4)) * (uint32_t)g.K + sch;
-    int mr = img0 * 2 + 4 * wave + ((lane & 31) >> 3);       // mean rows 4 wave .. + 3 (see gemm64c_kernel)
+    int mr = img0 * 2 + rl;
     mr = mr < g.M2 ? mr : g.M2 - 1;
     boff = (uint32_t)mr * (uint32_t)g.K + sch;
   }
@@ -637,20 +627,13 @@ __global__ __launch_bounds__(256) void gemm64c32_kernel(GemmArgs g) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(vo), "s"(sb), "s"(dst));
   };
-  auto dma_lo32 = [&](const T* sb, uint32_t elem_off, uint32_t dst) {
-    const uint32_t vo = elem_off * (uint32_t)sizeof(T);
-    uint32_t keep;
-    uint64_t keepx;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, %5\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep), "=&s"(keepx) : "v"(vo), "s"(sb), "s"(dst), "s"(0x00000000ffffffffull));
-  };
   auto issue_at = [&](int kt, int slot) {           // five pieces per wave and K-tile
     const uint32_t base = lds0 + (uint32_t)((slot % SNS32) * SST32 + wave * 1024);
     dma(A, aoff[0] + kt * 64, base);
     dma(A, aoff[1] + kt * 64, base + 4096);
     dma(W, woff + kt * 64, base + 8192);
     dma(dW, woff + kt * 64, base + 12288);
-    dma_lo32(AB, boff + kt * 64, base - wave * 512 + 16384);
+    dma(AB, boff + kt * 64, base + 16384);
   };
   f32x4 acc[2], acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
   acc[0] = acc2;
