@@ -846,18 +846,21 @@ def test_bench_starts_its_own_ranks_when_typed_without_a_launcher():
 
 @pytest.mark.gpu
 def test_tokens_are_the_same_whichever_gemm_kernel_computes_them():
-    """Batch sizes on both sides of the kernel choices in csrc/encoder.hip -- gemm64_kernel up to 2047 rows (B <= 7), the
+    """Batch sizes on both sides of the kernel choices in csrc/encoder.hip -- the small-batch GEMMs up to 2047 rows (B <= 7: 64 x 64
+    tiles, and 64 x 32 tiles for the two residual GEMMs while the 64 x 64 grid fills less than half of the chip, B <= 2), the
     256x256 kernel above, with and without peeled tail rows -- give an image the same patch tokens, bit for bit."""
     from hypervla.config import FULL
     from hypervla.model import HyperVLA
     from hypervla.synthetic import synthetic_images
     m = HyperVLA.from_synthetic(FULL, max_batch=40)
     im = synthetic_images(40, FULL)[:, 0]
-    ref = m.encode_images(im[:1]).cpu()                      # B = 1: 257 rows, gemm64_kernel
-    for B, pos in ((3, 0), (7, 0), (8, 0), (9, 0), (40, 0)):
+    ref = m.encode_images(im[:1]).cpu()                      # B = 1: 257 rows, gemm64c_kernel / gemm64c32_kernel
+    for B, pos in ((2, 0), (3, 0), (7, 0), (8, 0), (9, 0), (40, 0)):
         tok = m.encode_images(im[:B]).cpu()
         assert torch.equal(tok[pos], ref[0]), B
     last = m.encode_images(im[39:40]).cpu()
     assert torch.equal(m.encode_images(im).cpu()[39], last[0])
     mixed = m.encode_images(np.ascontiguousarray(im[[5, 0, 39, 0]])).cpu()
     assert torch.equal(mixed[1], ref[0]) and torch.equal(mixed[3], ref[0]) and torch.equal(mixed[2], last[0])
+    pair = m.encode_images(np.ascontiguousarray(im[[39, 0]])).cpu()             # B = 2: the second image's rows straddle 64-row tiles
+    assert torch.equal(pair[1], ref[0]) and torch.equal(pair[0], last[0])
