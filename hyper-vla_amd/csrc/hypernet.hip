@@ -2,15 +2,18 @@
 // hypervla/components/hypernetwork.py:99-233; Transformer, transformer.py:127-262).
 //
 //   ctx_encoder_kernel  one workgroup per episode: token/image projections + position embeddings,
-//                       the masked 6-layer context Transformer and the final scale, all in exact f32
-//                       on the VALU with the 34 x 128 token block resident in LDS (84 MFLOP/episode,
-//                       once per episode -> latency, not throughput, is what matters here).
+//                       the masked 6-layer context Transformer and the final scale, all in exact f32 with the
+//                       34 x 128 token block resident in LDS: the dense layers and the attention on the
+//                       matrix cores (v_mfma_f32_16x16x4_f32 multiplies and accumulates in f32), LayerNorm
+//                       and softmax on the VALU (84 MFLOP/episode, once per episode -> latency, not
+//                       throughput, is what matters here).
 //   weightgen_kernel    the 73 output heads collapsed into ONE GEMM  theta = ctx @ W_cat + b_cat,
 //                       computed transposed (theta^T tile = W_cat^T tile x ctx^T) with split-bf16
 //                       MFMA (3 x v_mfma_f32_32x32x16_bf16, ~2^-16 relative) so that each lane ends up
 //                       holding 16 consecutive packed positions of one episode and stores them
 //                       straight into the policy kernel's arena layout (layout.h).  HBM-bound:
-//                       reads W_cat once (hi+lo planes), writes the arena once.
+//                       reads W_cat once (hi+lo planes), writes the arena once; the ctx tiles reach the
+//                       four waves of a workgroup through LDS (LDS-DMA, one tile ahead).
 //   export_theta_kernel arena -> reference-order theta[B, G] (parity tests / `base_params` views).
 #include "common.h"
 #include "kernels.h"
