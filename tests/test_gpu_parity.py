@@ -2,7 +2,7 @@
 with the float64 numpy oracle on the same seeded inputs, and with the committed golden fixtures.
 
 Tolerances (floating point path; BASELINE.json north_star: actions within 1e-3 of the reference):
-  context embedding   exact-f32 VALU kernel                   max |d| <= 2e-5
+  context embedding   exact-f32 kernel (f32 MFMA + VALU)       max |d| <= 2e-5
   generated theta     split-bf16 MFMA (~2^-16 relative)       max |d| <= 1e-4
   policy from tokens  split-bf16 MFMA                         action MAE <= 1e-4, max <= 1e-3
   encoder tokens      fp16 operands, f32 accumulate           rms <= 2e-3 (bf16: 1.2e-2)
@@ -64,6 +64,33 @@ def test_generate_context_and_theta(mid):
     assert k.shape == (mid["B"], 4, 16, 64)
     np.testing.assert_allclose(k, mid["bp"]["encoder_Transformer_0_encoderblock_1_MultiHeadDotProductAttention_0_out_kernel"], atol=1e-4)
     assert tasks["pad_mask_dict"]["language_instruction"].all()
+
+
+@pytest.mark.parametrize("ctx_dim,ctx_heads,ctx_mlp,tokens", [(64, 4, 128, 12), (32, 2, 64, 20), (128, 8, 512, 32)])
+def test_generate_at_other_context_geometries(ctx_dim, ctx_heads, ctx_mlp, tokens):
+    """The context encoder's MFMA tiling and the weight generation's LDS staging at the other widths the library accepts
+    (C = 64 / 32: fewer column tiles than waves, k halves, KS = 4 / 2 ctx rows; head_dim 16 = one d tile; T + 2 rows in one,
+    two or three 16-row tiles), ragged batch, against the float64 oracle."""
+    _need_gpu()
+    import dataclasses
+    from hypervla import synthetic as syn
+    from hypervla.config import MID, generated_leaves
+    from hypervla.model import HyperVLA
+    from oracle import hvla_ref_np as onp
+    g = dataclasses.replace(MID, ctx_dim=ctx_dim, ctx_heads=ctx_heads, ctx_mlp=ctx_mlp, lang_tokens=tokens)
+    B = 37                                          # two episode tiles, the second ragged
+    P = syn.synthetic_params(g)
+    m = HyperVLA.from_synthetic(g, max_batch=40)
+    leaves = generated_leaves(g)
+    ins, st = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g)
+    bp, ctx_ref = onp.create_tasks(P, g, leaves, ins, st)
+    w, _, _ = m.create_tasks(instruction_dict=ins, initial_state=st)
+    theta, ctx = w.export()
+    theta, ctx = theta.cpu().numpy().astype(np.float64), ctx.cpu().numpy().astype(np.float64)
+    assert np.abs(ctx - ctx_ref[:, 0]).max() <= 2e-5
+    ref = np.concatenate([bp[l.flat_name].reshape(B, -1) for l in leaves], 1)
+    d = np.abs(theta - ref)
+    assert d.max() <= 1e-4, (d.max(), np.unravel_index(d.argmax(), d.shape))
 
 
 def test_policy_from_oracle_tokens(mid):
