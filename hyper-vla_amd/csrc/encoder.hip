@@ -769,8 +769,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int nbm = g.nbm, nbn = g.N / HBN_;
-  const int ntiles = nbm * nbn;
+  const int nbm = g.nbm, nbn = (g.N + HBN_ - 1) / HBN_;     // N % 64 == 0; a last tile column narrower than 256 (DINOv2-small: N = 384, 1152)
+  const int ntiles = nbm * nbn;                             // stages valid W rows again for the missing ones and its surplus waves store nothing
   const int GN = nbn % 4 == 0 ? 4 : (nbn % 3 == 0 ? 3 : (nbn % 2 == 0 ? 2 : 1));
   // virtual block id v (= blockIdx.x, + k * gridDim.x in the persistent form: gridDim.x is a multiple of 8, so a workgroup
   // stays in its XCD's id range) -> tile row tm, tile column origin n0.  Inside an XCD's contiguous id range: chunks of 8
@@ -803,6 +803,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const T* abase = A + (size_t)m0 * g.K;
   const T* wbase = W + (size_t)n0 * g.K;
+  int wn0 = n0;                                       // first column of the tile whose W rows `stage` is fetching
   const int KT = g.K / 64;
   auto stage = [&](auto hc, int kt) {              // half-tile hc of K-tile kt into buffer kt & 1
     constexpr int h = decltype(hc)::value;
@@ -815,7 +816,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       // destination) is compiler-reserved: it is saved, written, used and restored inside the one statement (guide 5.7;
       // an "m0" clobber is only a warning).  No "memory" clobber: it would make every issue wait for the fragment reads
       // in flight (barriers / counted waits order the DMA).
-      const T* sb = (h < 2 ? abase : wbase) + ((size_t)j * 64 * g.K + kt * 64);
+      const int jw = (h < 2 || wn0 + 64 * j < g.N) ? j : 0;           // (wave-uniform) a W row group past N: group 0 again, its products are dropped
+      const T* sb = (h < 2 ? abase : wbase) + ((size_t)jw * 64 * g.K + kt * 64);
       const uint32_t dst = lds0 + (uint32_t)(buf * 65536 + wave * 1024 + (h >> 1) * 32768 + j * 8192);
       const uint32_t vo = h < 2 ? lane_a : lane_w;
       uint32_t keep;
@@ -923,8 +925,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     // are fetched and WAITED FOR before the next tile's DMA goes out: the compiler does not see the hand-issued DMA, so a
     // wait it places after that point is a vmcnt(0) that would drain the prefetch
     const float* brow = (EPI != EPI_PATCH && g.corr) ? g.corr + ((size_t)ctm * 2 + wm) * g.N : g.bias;   // this wave row's half of the image
-    f32x4 pb4 = *reinterpret_cast<const f32x4*>(brow + cn0 + wn * 64 + 4 * fr), pl4 = pb4;
-    if constexpr (EPI == EPI_RES) pl4 = *reinterpret_cast<const f32x4*>(g.aux + cn0 + wn * 64 + 4 * fr);
+    const bool wvalid = cn0 + wn * 64 < g.N;          // (wave-uniform) this wave's 64 columns exist
+    f32x4 pb4 = f32x4{0.f, 0.f, 0.f, 0.f}, pl4 = pb4;
+    if (wvalid) {
+      pb4 = *reinterpret_cast<const f32x4*>(brow + cn0 + wn * 64 + 4 * fr);
+      pl4 = pb4;
+      if constexpr (EPI == EPI_RES) pl4 = *reinterpret_cast<const f32x4*>(g.aux + cn0 + wn * 64 + 4 * fr);
+    }
     asm volatile("" : "+v"(pb4), "+v"(pl4));
     if constexpr (PERSIST) {
       vb += gridDim.x;
@@ -934,13 +941,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         m0 = g.tile_row0 + tm * g.tile_stride;
         abase = A + (size_t)m0 * g.K;
         wbase = W + (size_t)n0 * g.K;
+        wn0 = n0;
         __builtin_amdgcn_sched_barrier(0);            // the wait below counts the epilogue's stores as issued AFTER this DMA:
         stage(H0{}, 0); stage(H1{}, 0); stage(H2{}, 0); stage(H3{}, 0);
         stage(H0{}, 1); stage(H1{}, 1);
         __builtin_amdgcn_sched_barrier(0);            // nothing may be scheduled across it in either direction
       }
     }
-    if constexpr (EPI == EPI_GELU) {
+    if (!wvalid) {
+      // nothing to store
+    } else if constexpr (EPI == EPI_GELU) {
       if (g.colmean) {
         // mean rows of this tile's rounded outputs for the fc2 compensation, one per WAVE ROW (= half of the image): lane sums
         // its 32 rows (ascending, in the operand type), the four lanes that share the columns combine in f32 as
@@ -971,7 +981,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     constexpr int WAITN = (PRO_DMA - PRO_DMA_KT0) + EpiVmem<EPI>::min_ops;
     static_assert(EpiVmem<EPI>::min_ops >= 32, "an epilogue issues at least one store per row of the wave tile");
     static_assert(WAITN >= 63 || WAITN == 36, "the s_waitcnt immediates below are written for these two counts");
-    if constexpr (WAITN >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    if (!wvalid) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRO_DMA - PRO_DMA_KT0) : "memory");     // (no epilogue operations behind the DMA)
+    else if constexpr (WAITN >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
   }
 #undef HVLA_BAR
@@ -1676,7 +1687,9 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     GemmArgs a{A, Wt, M, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
     a.hsplit = hsplit;
     const bool fits32 = (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
-    const bool aligned = P == HBM_ && N % HBN_ == 0 && M > G64_MAXM && K >= 128 && K % 64 == 0 && fits32;
+    // N % 256 != 0 (DINOv2-small: 384, 1152): the last tile column is 64, 128 or 192 wide, the rest of its MFMAs wasted (33 % at
+    // N = 384) -- still twice as fast as the 128 x 128 register-staged kernel
+    const bool aligned = P == HBM_ && N % SBN == 0 && N >= HBN_ && M > G64_MAXM && K >= 128 && K % 64 == 0 && fits32;
     pf.begin(CAT_COMP, st);
     if (aligned) {
       GemmArgs c = a;                                  // the B CLS rows (+ the B mean rows -> ws.corr)
@@ -1694,7 +1707,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
         hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
       }
       pf.end(CAT_COMP, st);
-      const int nbn = N / HBN_;
+      const int nbn = (N + HBN_ - 1) / HBN_;
       a.corr = comp ? ws.corr : nullptr;
       a.nbm = B; a.tile_row0 = 1; a.tile_stride = S; a.colmean = colmean;
       const size_t lds = 131072;
@@ -1774,10 +1787,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     const int Mp = B * P;
     GemmArgs a{ws.g, w.w_patch, Mp, E, Kp, w.b_patch, w.pos, ws.x, P, S, 0, 1.f / 256.f};
     const bool fits32 = (size_t)Mp * Kp < (1ull << 31);
-    if (Mp % HBM_ == 0 && E % HBN_ == 0 && Mp > G64_MAXM && fits32) {
+    if (Mp % HBM_ == 0 && E % SBN == 0 && E >= HBN_ && Mp > G64_MAXM && fits32) {
       a.nbm = Mp / HBM_; a.tile_row0 = 0; a.tile_stride = HBM_;
-      if ((a.nbm * (E / HBN_)) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true>), dim3(ncu), dim3(512), 131072, st, a);
-      else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false>), dim3(a.nbm * (E / HBN_)), dim3(512), 131072, st, a);
+      const int nbn = (E + HBN_ - 1) / HBN_;
+      if ((a.nbm * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true>), dim3(ncu), dim3(512), 131072, st, a);
+      else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false>), dim3(a.nbm * nbn), dim3(512), 131072, st, a);
     } else if (Mp <= G64_MAXM && fits32 && E % SBN == 0) {
       hipLaunchKernelGGL((gemm64_kernel<Op, EPI_PATCH>), dim3(((Mp + SBM - 1) / SBM) * (E / SBN)), dim3(256), SNS * 16384, st, a);
     } else {
