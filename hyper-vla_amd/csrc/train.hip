@@ -134,12 +134,12 @@ __device__ __forceinline__ void tie(StageRegs<4, false>& r) {
 }
 #undef HVLA_T
 
-template <bool T, int BR, bool VEC>
+template <bool T, int BR, bool VEC, int NTH = 256>
 __device__ __forceinline__ void stage_load(const float* __restrict__ P, int ld, int r0, int R, int k0, int kend,
-                                           StageRegs<BR * 8 / 256, VEC>& out) {
+                                           StageRegs<BR * 8 / NTH, VEC>& out) {
 #pragma unroll
-  for (int j = 0; j < BR * 8 / 256; ++j) {
-    const int idx = threadIdx.x + j * 256;
+  for (int j = 0; j < BR * 8 / NTH; ++j) {
+    const int idx = threadIdx.x + j * NTH;
     const int r = r0 + (T ? (idx % (BR / 4)) * 4 : idx >> 3), k = k0 + (T ? idx / (BR / 4) : (idx & 7) * 4);
     const bool ok = r < R && k < kend;
     const float* p = P + (T ? (long)k * ld + r : (long)r * ld + k);     // the 4 elements of a piece are adjacent in memory
@@ -157,11 +157,11 @@ __device__ __forceinline__ void stage_load(const float* __restrict__ P, int ld, 
     }
   }
 }
-template <bool T, int BR, bool VEC>
-__device__ __forceinline__ void stage_store(__bf16* __restrict__ hi, __bf16* __restrict__ lo, const StageRegs<BR * 8 / 256, VEC>& in) {
+template <bool T, int BR, bool VEC, int NTH = 256>
+__device__ __forceinline__ void stage_store(__bf16* __restrict__ hi, __bf16* __restrict__ lo, const StageRegs<BR * 8 / NTH, VEC>& in) {
 #pragma unroll
-  for (int j = 0; j < BR * 8 / 256; ++j) {
-    const int idx = threadIdx.x + j * 256;
+  for (int j = 0; j < BR * 8 / NTH; ++j) {
+    const int idx = threadIdx.x + j * NTH;
     const int o = T ? (idx / (BR / 4)) * (BR + 32) + (idx % (BR / 4)) * 4
                     : (idx >> 3) * 32 + ((((idx & 7) >> 1) ^ ((idx >> 4) & 3)) << 3) + (idx & 1) * 4;   // row = idx >> 3, see load_frag
     bf16x4 h, l;
@@ -210,15 +210,19 @@ __device__ __forceinline__ Split8 load_frag(const __bf16* hi, const __bf16* lo, 
   return f;
 }
 
+// BM = 256 (with BN = 128): EIGHT waves as 4 x 2, the same 64 x 64 per wave -- for problems whose 128 x 128 grid is between one and
+// two workgroups per CU (N = 768 at 8 224 rows: 390 tiles, 134 CUs with two and 122 with one; as 256 x 128 it is 198 tiles, one
+// round, and a thread splits 24 instead of 32 values per k step).
 template <bool TA, bool TB, int BM, int BN, bool VEC>
-__global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
-  constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, IN = WN / 32;
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void bgemm3_kernel(BG g) {
+  constexpr int NTH = BM == 256 ? 512 : 256;               // threads
+  constexpr int WM = BM == 256 ? 64 : BM / 2, WN = BN / 2, IM = WM / 32, IN = WN / 32;
   constexpr bool SA = TA, SB = !TB;                       // staging flavour: row-contiguous source?
   constexpr int NA = SA ? 32 * (BM + 32) : BM * 32, NB = SB ? 32 * (BN + 32) : BN * 32;
   // k steps of global loads in flight (register stages): three float4 stages, or two when every piece is 4 dwords
   // (the 6-bit vmcnt could not count three of those)
   constexpr int NST = VEC ? 3 : 2;
-  constexpr int PA = BM * 8 / 256, PB = BN * 8 / 256;     // float4 pieces per thread and stage
+  constexpr int PA = BM * 8 / NTH, PB = BN * 8 / NTH;     // float4 pieces per thread and stage
   constexpr int LPS = (PA + PB) * (VEC ? 1 : 4);          // load instructions per stage
   __shared__ __attribute__((aligned(16))) __bf16 Ah[NA], Al[NA], Bh[NB], Bl[NB];
   const int zb = blockIdx.z / g.ksplit, kc = blockIdx.z % g.ksplit;
@@ -242,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
   StageRegs<PB, VEC> rb[NST];
 #pragma unroll
   for (int s2 = 0; s2 < NST; ++s2) {                      // steps past kend read the block of zeros
-    stage_load<SA, BM, VEC>(A, g.lda, m0, g.M, kbeg + 32 * s2, kend, ra[s2]);
-    stage_load<SB, BN, VEC>(B, g.ldb, n0, g.N, kbeg + 32 * s2, kend, rb[s2]);
+    stage_load<SA, BM, VEC, NTH>(A, g.lda, m0, g.M, kbeg + 32 * s2, kend, ra[s2]);
+    stage_load<SB, BN, VEC, NTH>(B, g.ldb, n0, g.N, kbeg + 32 * s2, kend, rb[s2]);
   }
   // Whole groups of NST steps (a step past kend multiplies staged zeros), every step issues its refill: the number of
   // loads in flight is the same at every wait, so the wait for the oldest stage is the constant vmcnt((NST - 1) * LPS).
@@ -256,13 +260,13 @@ __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * LPS) : "memory");     // the oldest stage has landed
       tie(ra[s2]);
       tie(rb[s2]);
-      stage_store<SA, BM, VEC>(Ah, Al, ra[s2]);
-      stage_store<SB, BN, VEC>(Bh, Bl, rb[s2]);
+      stage_store<SA, BM, VEC, NTH>(Ah, Al, ra[s2]);
+      stage_store<SB, BN, VEC, NTH>(Bh, Bl, rb[s2]);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the LDS image is complete
       // refill this register stage NST steps ahead
 #ifndef HVLA_ABL_NOLOAD      // timing ablation only
-      stage_load<SA, BM, VEC>(A, g.lda, m0, g.M, kcur + 32 * NST, kend, ra[s2]);
-      stage_load<SB, BN, VEC>(B, g.ldb, n0, g.N, kcur + 32 * NST, kend, rb[s2]);
+      stage_load<SA, BM, VEC, NTH>(A, g.lda, m0, g.M, kcur + 32 * NST, kend, ra[s2]);
+      stage_load<SB, BN, VEC, NTH>(B, g.ldb, n0, g.N, kcur + 32 * NST, kend, rb[s2]);
 #endif
 #pragma unroll
       for (int kk = 0; kk < 32; kk += 16) {
@@ -335,10 +339,11 @@ __global__ __launch_bounds__(256, 2) void bgemm3_kernel(BG g) {
 
 template <int BM, int BN, bool VEC>
 static void launch_bgemm3(hipStream_t st, bool ta, bool tb, const BG& g, dim3 grid) {
-  if (!ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<false, false, BM, BN, VEC>), grid, dim3(256), 0, st, g);
-  else if (!ta && tb) hipLaunchKernelGGL((bgemm3_kernel<false, true, BM, BN, VEC>), grid, dim3(256), 0, st, g);
-  else if (ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<true, false, BM, BN, VEC>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((bgemm3_kernel<true, true, BM, BN, VEC>), grid, dim3(256), 0, st, g);
+  constexpr int NTH = BM == 256 ? 512 : 256;
+  if (!ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<false, false, BM, BN, VEC>), grid, dim3(NTH), 0, st, g);
+  else if (!ta && tb) hipLaunchKernelGGL((bgemm3_kernel<false, true, BM, BN, VEC>), grid, dim3(NTH), 0, st, g);
+  else if (ta && !tb) hipLaunchKernelGGL((bgemm3_kernel<true, false, BM, BN, VEC>), grid, dim3(NTH), 0, st, g);
+  else hipLaunchKernelGGL((bgemm3_kernel<true, true, BM, BN, VEC>), grid, dim3(NTH), 0, st, g);
 }
 
 // the exact-f32 matrix instruction (bitwise fmaf chains) instead of the split-bf16 path: libhvla_bench.so only
@@ -371,6 +376,12 @@ void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
       return ((uintptr_t)p % 16 == 0) && ld % 4 == 0 && s0 % 4 == 0 && s1 % 4 == 0 && extent % 4 == 0;
     };
     const bool vec = al(g.A, g.lda, g.sA0, g.sA1, ta ? g.M : g.K) && al(g.B, g.ldb, g.sB0, g.sB1, tb ? g.K : g.N);
+    // between one and two 128 x 128 workgroups per CU: 256 x 128 tiles (eight waves) make it one round
+    const long t128 = (long)grid.x * grid.y * grid.z, t256 = (long)grid.x * ((g.M + 255) / 256) * grid.z;
+    if (T == 128 && vec && t128 > want && t128 <= 2 * want && t256 <= want) {
+      launch_bgemm3<256, 128, true>(st, ta, tb, g, dim3(grid.x, (g.M + 255) / 256, grid.z));
+      return;
+    }
     if (T == 128) { if (vec) launch_bgemm3<128, 128, true>(st, ta, tb, g, grid); else launch_bgemm3<128, 128, false>(st, ta, tb, g, grid); }
     else { if (vec) launch_bgemm3<64, 64, true>(st, ta, tb, g, grid); else launch_bgemm3<64, 64, false>(st, ta, tb, g, grid); }
     return;
