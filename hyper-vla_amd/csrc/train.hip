@@ -896,7 +896,9 @@ static Off leaf_offsets(const Geom& g) {
 
 // Transformer block forward / backward on rows [nb][S][D] with weights at W + b * wstride (wstride = G for
 // the per-episode policy, 0 for the shared context encoder).  Buffers for one layer:
-struct BlkBuf { float *x_in, *mean0, *rstd0, *q, *k, *v, *p, *o, *x_mid, *mean1, *rstd1, *u, *y1, *y2; };
+// h, h2, g (the two LayerNorm outputs and the GELU output): kept per block when the plan has room for them (the backward pass
+// then reads them instead of recomputing them: two LayerNorm passes and one GELU pass per block), else nullptr
+struct BlkBuf { float *x_in, *mean0, *rstd0, *q, *k, *v, *p, *o, *x_mid, *mean1, *rstd1, *u, *y1, *y2, *h, *h2, *g; };
 struct BlkW { const float *l0s, *l0b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *l1s, *l1b, *w1, *b1, *w2, *b2, *ls1, *ls2; };
 struct BlkG { float *l0s, *l0b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *l1s, *l1b, *w1, *b1, *w2, *b2, *ls1, *ls2; };
 // block flavour: the flax Encoder1DBlock of the context encoder / generated policy (tanh GELU, masked attention) or the
@@ -919,10 +921,13 @@ static void linear_dx(hipStream_t st, int nb, int S, long ws, const float* dY, c
 static void block_fwd(hipStream_t st, int nb, int S, int D, int H, int F, long ws, const BlkW& w, const BlkBuf& a,
                       float* x_out, const BlkTmp& t, const BlkOpt& op) {
   const int hd = D / H, rows = nb * S;
-  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t.h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);
-  linear(st, nb, S, ws, t.h, w.wq, w.bq, a.q, D, D, 0);
-  linear(st, nb, S, ws, t.h, w.wk, w.bk, a.k, D, D, 0);
-  linear(st, nb, S, ws, t.h, w.wv, w.bv, a.v, D, D, 0);
+  float* const h = a.h ? a.h : t.h;
+  float* const h2 = a.h2 ? a.h2 : t.h;
+  float* const gg = a.g ? a.g : t.g;
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);
+  linear(st, nb, S, ws, h, w.wq, w.bq, a.q, D, D, 0);
+  linear(st, nb, S, ws, h, w.wk, w.bk, a.k, D, D, 0);
+  linear(st, nb, S, ws, h, w.wv, w.bv, a.v, D, D, 0);
   // scores[b][h] = q_h k_h^T / sqrt(hd)
   bgemm(st, false, true, BG{a.q, a.k, a.p, nullptr, S, S, hd, D, D, S, (long)S * D, hd, (long)S * D, hd, (long)H * S * S, (long)S * S, 0, H, 1.f / sqrtf((float)hd), 0}, nb);
   KL(softmax_fwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, nb * H, S, S, op.mask_mode, op.am, H);
@@ -934,15 +939,15 @@ static void block_fwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
     (void)hipMemcpyAsync(a.x_mid, a.x_in, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
     linear(st, nb, S, ws, a.o, w.wo, w.bo, a.x_mid, D, D, 1);
   }
-  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t.h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);
-  linear(st, nb, S, ws, t.h, w.w1, w.b1, a.u, D, F, 0);
-  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, t.g, (long)rows * F, op.gelu_erf);
+  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, h2, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);
+  linear(st, nb, S, ws, h2, w.w1, w.b1, a.u, D, F, 0);
+  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, gg, (long)rows * F, op.gelu_erf);
   if (w.ls2) {
-    linear(st, nb, S, ws, t.g, w.w2, w.b2, a.y2, F, D, 0);
+    linear(st, nb, S, ws, gg, w.w2, w.b2, a.y2, F, D, 0);
     KL(scale_add_kernel, g1((long)rows * D), dim3(256), x_out, a.x_mid, a.y2, w.ls2, (long)rows * D, D);
   } else {
     (void)hipMemcpyAsync(x_out, a.x_mid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
-    linear(st, nb, S, ws, t.g, w.w2, w.b2, x_out, F, D, 1);
+    linear(st, nb, S, ws, gg, w.w2, w.b2, x_out, F, D, 1);
   }
 }
 
@@ -974,18 +979,20 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
     }
   };
   // ---- MLP: x_out = x_mid + [ls2 (.)] (gelu(LN1(x_mid) W1 + b1) W2 + b2)
-  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t.h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);   // recompute h2
-  KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, t.g, (long)rows * F, op.gelu_erf);                           // recompute g
+  const float* h2 = a.h2 ? a.h2 : t.h;
+  const float* gg = a.g ? a.g : t.g;
+  if (!a.h2) KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_mid, t.h, a.mean1, a.rstd1, w.l1s, w.l1b, ws, rows, S, D);   // recompute h2
+  if (!a.g) KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, t.g, (long)rows * F, op.gelu_erf);                           // recompute g
   const float* dy = dx;
   if (w.ls2) {
     KL(ls_bwd_kernel, dim3((D + 63) / 64, (rows + 63) / 64), dim3(64), dx, a.y2, w.ls2, t.y, gw.ls2, rows, D);
     dy = t.y;
   }
-  wgrad(t.g, F, dy, D, gw.w2);
+  wgrad(gg, F, dy, D, gw.w2);
   bgrad(dy, D, gw.b2);
   linear_dx(st, nb, S, ws, dy, w.w2, t.d, F, D, 0);                                                                     // dg = dy W2^T
   KL(gelu_bwd_kernel, g1((long)rows * F), dim3(256), a.u, t.d, (long)rows * F, op.gelu_erf);                           // du
-  wgrad(t.h, D, t.d, F, gw.w1);
+  wgrad(h2, D, t.d, F, gw.w1);
   bgrad(t.d, F, gw.b1);
   linear_dx(st, nb, S, ws, t.d, w.w1, t.g, D, F, 0);                                                                    // dh2 -> t.g[rows][D]
   ln_bwd(a.x_mid, t.g, a.mean1, a.rstd1, w.l1s, gw.l1s, gw.l1b);
@@ -1006,13 +1013,14 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
   const float sc = 1.f / sqrtf((float)hd);
   bgemm(st, false, false, BG{t.dp, a.k, t.dq, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);   // dq = ds k / sqrt(hd)
   bgemm(st, true, false, BG{t.dp, a.q, t.dk, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);    // dk = ds^T q / sqrt(hd)
-  KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t.h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);      // recompute h
+  const float* h = a.h ? a.h : t.h;
+  if (!a.h) KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t.h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);      // recompute h
   const float* dqkv[3] = {t.dq, t.dk, t.dv};
   float* gWm[3] = {gw.wq, gw.wk, gw.wv};
   float* gBm[3] = {gw.bq, gw.bk, gw.bv};
   const float* Wm[3] = {w.wq, w.wk, w.wv};
   for (int i = 0; i < 3; ++i) {
-    wgrad(t.h, D, dqkv[i], D, gWm[i]);
+    wgrad(h, D, dqkv[i], D, gWm[i]);
     bgrad(dqkv[i], D, gBm[i]);
     linear_dx(st, nb, S, ws, dqkv[i], Wm[i], t.g, D, D, i > 0);                                                         // dh
   }
@@ -1036,6 +1044,8 @@ static Plan make_plan(const Geom& g, int B, bool enc, float* base) {
     b.v = take(nb * s * d); b.p = take(nb * h * s * s); b.o = take(nb * s * d); b.x_mid = take(nb * s * d); b.mean1 = take(nb * s);
     b.rstd1 = take(nb * s); b.u = take(nb * s * f);
     b.y1 = ls ? take(nb * s * d) : nullptr; b.y2 = ls ? take(nb * s * d) : nullptr;
+    // 288 GB of HBM: the LayerNorm and GELU outputs are kept (B = 32 with the encoder trained: 1.8 GB) instead of recomputed
+    b.h = take(nb * s * d); b.h2 = take(nb * s * d); b.g = take(nb * s * f);
     return b;
   };
   const long S = g.S(), D = g.D, H = g.H, F = g.M, Sc = g.T + 2, C = g.C, Hc = g.ctx_heads, Fc = g.ctx_mlp;
