@@ -603,6 +603,42 @@ __global__ void colsum4_kernel(const float* __restrict__ x, float* __restrict__ 
   for (int c = 0; c < 4; ++c) unsafeAtomicAdd(o + c, s[c]);
 }
 
+// The long shared-parameter reductions of the encoder (8 224 rows x 768 / 3 072 columns): the two kernels above have 800-1 500
+// waves of 8 KB in flight for 25-100 MB (17-23 us for the narrow matrices: 1.5 TB/s).  Here a workgroup is eight waves x 8 rows
+// x 2 batches, every row load of a batch in flight at once, the eight partial rows combined through LDS, one atomic per column
+// and workgroup (four waves x 8 rows x 1 batch, twice the atomics of before, was SLOWER than the old kernels: 37 us).
+constexpr int CSB_WAVES = 8, CSB_BATCH = 2;          // 128 rows per workgroup: half the atomics of the 64-row chunks above
+__global__ __launch_bounds__(CSB_WAVES * 64) void colsum4b_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int N) {
+  __shared__ f32x4 part[CSB_WAVES][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = (blockIdx.x * 64 + lane) * 4;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+#pragma unroll
+    for (int bt = 0; bt < CSB_BATCH; ++bt) {
+      const int r0 = (blockIdx.z * CSB_BATCH + bt) * (CSB_WAVES * 8) + wave * 8;
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u < rows ? r0 + u : rows - 1;
+        v[u] = *reinterpret_cast<const f32x4*>(x + (long)r * N + n);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + u < rows) s += v[u];
+    }
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    f32x4 t = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < CSB_WAVES; ++w) t += part[w][lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) unsafeAtomicAdd(out + n + c, t[c]);
+  }
+}
+
 // x0 assembly: rows < P already hold tokens.Wp + bp; row P = 0; += pos  (base_vit.py:182-204)
 __global__ void x0_finish_kernel(float* __restrict__ x, const float* __restrict__ pos, long pstride, int S, int D, int nb) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -965,7 +1001,9 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
     // the 4-column form wins on the narrow matrices of the policy / hypernetwork; on the encoder's 768- and 3072-wide ones
     // its fewer, fatter waves lose to the one-column form (17 vs 23 us)
     const bool v4 = N % 4 == 0 && N <= 512 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
-    if (shared && v4) KL(colsum4_kernel, dim3((N / 4 + 63) / 64, 1, (rows + 31) / 32), dim3(64), dY, dB, 0, rows, rows, N, 1);
+    if (shared && N % 4 == 0 && N > 512 && rows >= 2048 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0)
+      KL(colsum4b_kernel, dim3((N / 4 + 63) / 64, 1, (rows + CSB_WAVES * 8 * CSB_BATCH - 1) / (CSB_WAVES * 8 * CSB_BATCH)), dim3(CSB_WAVES * 64), dY, dB, rows, N);
+    else if (shared && v4) KL(colsum4_kernel, dim3((N / 4 + 63) / 64, 1, (rows + 31) / 32), dim3(64), dY, dB, 0, rows, rows, N, 1);
     else if (shared) KL(colsum_kernel, dim3((N + 63) / 64, 1, (rows + 63) / 64), dim3(64), dY, dB, 0, rows, rows, N, 1);
     else if (v4) KL(colsum4_kernel, dim3((N / 4 + 63) / 64, nb, (S + 31) / 32), dim3(64), dY, dB, gs, S, S, N, nb);
     else KL(colsum_kernel, dim3((N + 63) / 64, nb, (S + 63) / 64), dim3(64), dY, dB, gs, S, S, N, nb);
