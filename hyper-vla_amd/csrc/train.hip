@@ -445,6 +445,87 @@ __global__ void ln_bwd_kernel(const float* __restrict__ x, const float* __restri
   }
 }
 
+// LN backward for SHARED parameters in one pass (round 3; before: ln_bwd_kernel + ln_pgrad_kernel, each reading x and dy: 28 + 22 us
+// for 8 224 x 768): a workgroup of eight waves takes 64 rows, a wave its rows one after the other with x and dy of a row in
+// registers (float4, read once), dx (+)= r (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), and every lane keeps the dscale / dbias
+// sums of its columns; the waves are combined through LDS, one atomic per (workgroup, column).  D % 4 == 0, D <= 1024.
+constexpr int LNB_WAVES = 8;
+__global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_shared_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ scale, float* __restrict__ dx,
+                                                            float* __restrict__ dscale, float* __restrict__ dbias, int rows, int D,
+                                                            int accumulate) {
+  __shared__ f32x4 red[2][LNB_WAVES][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n4 = D / 4;
+  f32x4 sc[4], ga[4], gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    ga[i] = gb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sc[i] = c < n4 ? reinterpret_cast<const f32x4*>(scale)[c] : ga[i];
+  }
+  const int r0 = blockIdx.x * 64, r1 = r0 + 64 < rows ? r0 + 64 : rows;
+  const float invD = 1.f / (float)D;
+  for (int row = r0 + wave; row < r1; row += LNB_WAVES) {
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * D);
+    const f32x4* dr = reinterpret_cast<const f32x4*>(dy + (long)row * D);
+    f32x4* ox = reinterpret_cast<f32x4*>(dx + (long)row * D);
+    f32x4 xv[4], dv[4], old[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = dv[i] = old[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < n4) {
+        xv[i] = xr[c];
+        dv[i] = dr[c];
+        if (accumulate) old[i] = ox[c];
+      }
+    }
+    const float m = mean[row], r = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (lane + 64 * i < n4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[i][j] - m) * r, dxh = dv[i][j] * sc[i][j];
+          s1 += dxh;
+          s2 = fmaf(dxh, xh, s2);
+          ga[i][j] = fmaf(dv[i][j], xh, ga[i][j]);
+          gb[i][j] += dv[i][j];
+          xv[i][j] = xh;                     // keep xhat and dxhat for the second half
+          dv[i][j] = dxh;
+        }
+      }
+    }
+    for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= invD;
+    s2 *= invD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < n4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = old[i][j] + r * (dv[i][j] - s1 - xv[i][j] * s2);
+        ox[c] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[0][wave][lane + 64 * i] = ga[i], red[1][wave][lane + 64 * i] = gb[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * n4; c += LNB_WAVES * 64) {
+    const int which = c >= n4, cc = c - which * n4;
+    f32x4 t = red[which][0][cc];
+#pragma unroll
+    for (int w = 1; w < LNB_WAVES; ++w) t += red[which][w][cc];
+    float* o = (which ? dbias : dscale) + 4 * cc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(o + j, t[j]);
+  }
+}
+
 // shared LayerNorm parameters: dscale[c] += sum_r dy[r][c] xhat[r][c], dbias[c] += sum_r dy[r][c]; 64 rows per
 // block (blockIdx.y) reduced in registers, one atomic per (block, column) instead of one per element.
 __global__ void ln_pgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
@@ -1011,7 +1092,9 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
     else KL(colsum_kernel, dim3((N + 63) / 64, nb, (S + 63) / 64), dim3(64), dY, dB, gs, S, S, N, nb);
   };
   auto ln_bwd = [&](const float* x, const float* dy, const float* mean, const float* rstd, const float* sc, float* gs_, float* gb_) {
-    if (shared) {
+    if (shared && D % 4 == 0 && D <= 1024 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
+      KL(ln_bwd_shared_kernel, dim3((rows + 63) / 64), dim3(LNB_WAVES * 64), x, dy, mean, rstd, sc, dx, gs_, gb_, rows, D, 1);
+    } else if (shared) {
       KL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), x, dy, mean, rstd, sc, dx, (float*)nullptr, (float*)nullptr, 0, rows, S, D, 1);
       KL(ln_pgrad_kernel, dim3((D + 63) / 64, (rows + 63) / 64), dim3(64), x, dy, mean, rstd, gs_, gb_, rows, D);
     } else {
