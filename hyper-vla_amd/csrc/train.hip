@@ -566,6 +566,46 @@ __global__ void ls_bwd_kernel(const float* __restrict__ dx, const float* __restr
   unsafeAtomicAdd(dls + c, a);
 }
 
+// the same with float4 columns, eight waves x 8 rows x 2 batches per workgroup (all loads of a batch in flight), the dls partials
+// of the waves combined through LDS: 34 -> ~15 us for 8 224 x 768.  D % 4 == 0, 16-byte aligned rows.
+__global__ __launch_bounds__(512) void ls_bwd4_kernel(const float* __restrict__ dx, const float* __restrict__ y, const float* __restrict__ ls,
+                                                      float* __restrict__ dy, float* __restrict__ dls, int rows, int D) {
+  __shared__ f32x4 part[8][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c4 = blockIdx.x * 64 + lane, n4 = D / 4;
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c4 < n4) {
+    const f32x4 l = reinterpret_cast<const f32x4*>(ls)[c4];
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      const int r0 = (blockIdx.y * 2 + bt) * 64 + wave * 8;
+      f32x4 d[8], v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u < rows ? r0 + u : rows - 1;
+        d[u] = reinterpret_cast<const f32x4*>(dx + (long)r * D)[c4];
+        v[u] = reinterpret_cast<const f32x4*>(y + (long)r * D)[c4];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + u < rows) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] = fmaf(d[u][j], v[u][j], a[j]);
+          reinterpret_cast<f32x4*>(dy + (long)(r0 + u) * D)[c4] = d[u] * l;
+        }
+    }
+  }
+  part[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && c4 < n4) {
+    f32x4 t = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) t += part[w][lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dls + 4 * c4 + j, t[j]);
+  }
+}
+
 // DINOv2 input side (base_vit.py:111-122 + HF Dinov2Embeddings): normalised patch matrix [B*P][p*p*3] in the flax
 // conv kernel's (dy, dx, c) order, then x[b][0] = cls + pos[0], x[b][1+t] = patch_t W + b + pos[1+t].
 __global__ void im2col_f32_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int B, int HW, int p) {
@@ -1101,6 +1141,12 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
       KL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), x, dy, mean, rstd, sc, dx, gs_, gb_, gs, rows, S, D, 1);
     }
   };
+  auto ls_bwd = [&](const float* dxp, const float* y, const float* ls, float* dy, float* dls) {
+    if (D % 4 == 0 && rows >= 1024 && ((reinterpret_cast<uintptr_t>(dxp) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0)
+      KL(ls_bwd4_kernel, dim3((D / 4 + 63) / 64, (rows + 127) / 128), dim3(512), dxp, y, ls, dy, dls, rows, D);
+    else
+      KL(ls_bwd_kernel, dim3((D + 63) / 64, (rows + 63) / 64), dim3(64), dxp, y, ls, dy, dls, rows, D);
+  };
   // ---- MLP: x_out = x_mid + [ls2 (.)] (gelu(LN1(x_mid) W1 + b1) W2 + b2)
   const float* h2 = a.h2 ? a.h2 : t.h;
   const float* gg = a.g ? a.g : t.g;
@@ -1108,7 +1154,7 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
   if (!a.g) KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, t.g, (long)rows * F, op.gelu_erf);                           // recompute g
   const float* dy = dx;
   if (w.ls2) {
-    KL(ls_bwd_kernel, dim3((D + 63) / 64, (rows + 63) / 64), dim3(64), dx, a.y2, w.ls2, t.y, gw.ls2, rows, D);
+    ls_bwd(dx, a.y2, w.ls2, t.y, gw.ls2);
     dy = t.y;
   }
   wgrad(gg, F, dy, D, gw.w2);
@@ -1123,7 +1169,7 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
   // ---- attention: x_mid = x_in + [ls1 (.)] (o Wo + bo)
   dy = dx;
   if (w.ls1) {
-    KL(ls_bwd_kernel, dim3((D + 63) / 64, (rows + 63) / 64), dim3(64), dx, a.y1, w.ls1, t.y, gw.ls1, rows, D);
+    ls_bwd(dx, a.y1, w.ls1, t.y, gw.ls1);
     dy = t.y;
   }
   wgrad(a.o, D, dy, D, gw.wo);
