@@ -550,6 +550,14 @@ __global__ void scale_add_kernel(float* __restrict__ out, const float* __restric
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     out[i] = res[i] + ls[i % D] * y[i];
 }
+// float4 form (D % 4 == 0, 16-byte aligned): no 64-bit modulo per element
+__global__ void scale_add4_kernel(f32x4* __restrict__ out, const f32x4* __restrict__ res, const f32x4* __restrict__ y,
+                                  const f32x4* __restrict__ ls, long n4, int d4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 l = ls[(int)(i % d4)], r = res[i], v = y[i];
+    out[i] = f32x4{fmaf(l[0], v[0], r[0]), fmaf(l[1], v[1], r[1]), fmaf(l[2], v[2], r[2]), fmaf(l[3], v[3], r[3])};
+  }
+}
 // backward: dy = dx (.) ls ; dls[c] += sum_r dx[r][c] y[r][c]  (row chunks of 64 as in ln_pgrad_kernel)
 __global__ void ls_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ y, const float* __restrict__ ls,
                               float* __restrict__ dy, float* __restrict__ dls, int rows, int D) {
@@ -1077,6 +1085,12 @@ static void linear_dx(hipStream_t st, int nb, int S, long ws, const float* dY, c
   else bgemm(st, false, true, BG{dY, W, dX, nullptr, S, K, N, N, N, K, (long)S * N, 0, ws, 0, (long)S * K, 0, 0, 1, 1.f, acc}, nb);
 }
 
+static void scale_add(hipStream_t st, float* out, const float* res, const float* y, const float* ls, long n, int D) {
+  const bool v4 = D % 4 == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ls)) & 15) == 0;
+  if (v4) KL(scale_add4_kernel, g1(n / 4), dim3(256), reinterpret_cast<f32x4*>(out), reinterpret_cast<const f32x4*>(res), reinterpret_cast<const f32x4*>(y), reinterpret_cast<const f32x4*>(ls), n / 4, D / 4);
+  else KL(scale_add_kernel, g1(n), dim3(256), out, res, y, ls, n, D);
+}
+
 static void block_fwd(hipStream_t st, int nb, int S, int D, int H, int F, long ws, const BlkW& w, const BlkBuf& a,
                       float* x_out, const BlkTmp& t, const BlkOpt& op) {
   const int hd = D / H, rows = nb * S;
@@ -1093,7 +1107,7 @@ static void block_fwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
   bgemm(st, false, false, BG{a.p, a.v, a.o, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}, nb);
   if (w.ls1) {
     linear(st, nb, S, ws, a.o, w.wo, w.bo, a.y1, D, D, 0);
-    KL(scale_add_kernel, g1((long)rows * D), dim3(256), a.x_mid, a.x_in, a.y1, w.ls1, (long)rows * D, D);
+    scale_add(st, a.x_mid, a.x_in, a.y1, w.ls1, (long)rows * D, D);
   } else {
     (void)hipMemcpyAsync(a.x_mid, a.x_in, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
     linear(st, nb, S, ws, a.o, w.wo, w.bo, a.x_mid, D, D, 1);
@@ -1103,7 +1117,7 @@ static void block_fwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
   KL(gelu_fwd_kernel, g1((long)rows * F), dim3(256), a.u, gg, (long)rows * F, op.gelu_erf);
   if (w.ls2) {
     linear(st, nb, S, ws, gg, w.w2, w.b2, a.y2, F, D, 0);
-    KL(scale_add_kernel, g1((long)rows * D), dim3(256), x_out, a.x_mid, a.y2, w.ls2, (long)rows * D, D);
+    scale_add(st, x_out, a.x_mid, a.y2, w.ls2, (long)rows * D, D);
   } else {
     (void)hipMemcpyAsync(x_out, a.x_mid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st);
     linear(st, nb, S, ws, gg, w.w2, w.b2, x_out, F, D, 1);
