@@ -22,6 +22,8 @@ struct BG {
   int ksplit = 1;             // > 1: K is cut into ksplit chunks over blockIdx.z, reduced with atomics (accumulate != 0)
   int allow_split = 0;        // 1: the launcher may choose ksplit > 1 itself (deep-K gradient products; result then
                               //    depends on the order of the atomic adds in its last bits)
+  int a_padded = 0;           // 1: every row of A is followed by zeros up to a multiple of 4 elements inside lda (the attention
+                              //    matrices, row stride S rounded up): float4 staging may run over the row's end
 };
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0);
 

@@ -377,7 +377,8 @@ void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
     auto al = [](const float* p, int ld, long s0, long s1, int extent) {
       return ((uintptr_t)p % 16 == 0) && ld % 4 == 0 && s0 % 4 == 0 && s1 % 4 == 0 && extent % 4 == 0;
     };
-    const bool vec = al(g.A, g.lda, g.sA0, g.sA1, ta ? g.M : g.K) && al(g.B, g.ldb, g.sB0, g.sB1, tb ? g.K : g.N);
+    const int a_extent = ta ? g.M : g.K;
+    const bool vec = al(g.A, g.lda, g.sA0, g.sA1, g.a_padded && g.lda >= ((a_extent + 3) & ~3) ? 4 : a_extent) && al(g.B, g.ldb, g.sB0, g.sB1, tb ? g.K : g.N);
     // between one and two 128 x 128 workgroups per CU: 256 x 128 tiles (eight waves) make it one round
     const long t128 = (long)grid.x * grid.y * grid.z, t256 = (long)grid.x * ((g.M + 255) / 256) * grid.z;
     if (T == 128 && vec && t128 > want && t128 <= 2 * want && t256 <= want) {
@@ -641,11 +642,12 @@ __global__ void enc_x0_kernel(float* __restrict__ x, const float* __restrict__ c
 // masked softmax over the last dim of [nmat][R][Cc] in place.  mode 2: no mask; mode 0: policy mask (rows < R-1 cannot see
 // column Cc-1, base_vit.py:209-214); mode 1: context mask (hypernetwork.py:149-181) from attn_mask[b][T].
 __global__ void softmax_fwd_kernel(float* __restrict__ p, int nmat, int R, int Cc, int mode,
-                                   const int64_t* __restrict__ am, int heads) {
+                                   const int64_t* __restrict__ am, int heads, int ld) {      // ld >= Cc: row stride; [Cc, ld) is set to 0
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= nmat * R) return;
   const int mat = row / R, q = row % R;
-  float* pr = p + (long)row * Cc;
+  float* pr = p + (long)row * ld;
+  if (lane < ld - Cc) pr[Cc + lane] = 0.f;
   auto keep = [&](int k) {
     if (mode == 2) return true;                                    // DINOv2 encoder: dense attention
     if (mode == 0) return !(q < R - 1 && k == Cc - 1);
@@ -669,11 +671,12 @@ __global__ void softmax_fwd_kernel(float* __restrict__ p, int nmat, int R, int C
 }
 
 // ds = p * (dp - sum_k dp p), in place on dp
-__global__ void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int rows, int Cc) {
+__global__ void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int rows, int Cc, int ld) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const float* pr = p + (long)row * Cc;
-  float* dr = dp + (long)row * Cc;
+  const float* pr = p + (long)row * ld;
+  float* dr = dp + (long)row * ld;
+  if (lane < ld - Cc) dr[Cc + lane] = 0.f;                 // ds is the A operand of two float4-staged products: zeros behind the row
   float s = 0.f;
   for (int k = lane; k < Cc; k += 64) s += pr[k] * dr[k];
   for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -1102,9 +1105,17 @@ static void block_fwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
   linear(st, nb, S, ws, h, w.wk, w.bk, a.k, D, D, 0);
   linear(st, nb, S, ws, h, w.wv, w.bv, a.v, D, D, 0);
   // scores[b][h] = q_h k_h^T / sqrt(hd)
-  bgemm(st, false, true, BG{a.q, a.k, a.p, nullptr, S, S, hd, D, D, S, (long)S * D, hd, (long)S * D, hd, (long)H * S * S, (long)S * S, 0, H, 1.f / sqrtf((float)hd), 0}, nb);
-  KL(softmax_fwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, nb * H, S, S, op.mask_mode, op.am, H);
-  bgemm(st, false, false, BG{a.p, a.v, a.o, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}, nb);
+  // the S x S attention matrices have row stride Sp = S rounded up to 4 floats, zeros behind every row (written by the softmax
+  // kernels): as A operands they are staged with float4 loads like everything else (S = 257: the all-dword staging these four
+  // products per layer were left with cost 3.6 ms per step)
+  const int Sp = (S + 3) & ~3;
+  bgemm(st, false, true, BG{a.q, a.k, a.p, nullptr, S, S, hd, D, D, Sp, (long)S * D, hd, (long)S * D, hd, (long)H * S * Sp, (long)S * Sp, 0, H, 1.f / sqrtf((float)hd), 0}, nb);
+  KL(softmax_fwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, nb * H, S, S, op.mask_mode, op.am, H, Sp);
+  {
+    BG pv{a.p, a.v, a.o, nullptr, S, hd, S, Sp, D, D, (long)H * S * Sp, (long)S * Sp, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0};
+    pv.a_padded = 1;
+    bgemm(st, false, false, pv, nb);
+  }
   if (w.ls1) {
     linear(st, nb, S, ws, a.o, w.wo, w.bo, a.y1, D, D, 0);
     scale_add(st, a.x_mid, a.x_in, a.y1, w.ls1, (long)rows * D, D);
@@ -1190,12 +1201,15 @@ static void block_bwd(hipStream_t st, int nb, int S, int D, int H, int F, long w
   bgrad(dy, D, gw.bo);
   linear_dx(st, nb, S, ws, dy, w.wo, t.d, D, D, 0);                                                                     // do
   // dp = do_h v_h^T ; dv_h = p^T do_h
-  bgemm(st, false, true, BG{t.d, a.v, t.dp, nullptr, S, S, hd, D, D, S, (long)S * D, hd, (long)S * D, hd, (long)H * S * S, (long)S * S, 0, H, 1.f, 0}, nb);
-  bgemm(st, true, false, BG{a.p, t.d, t.dv, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}, nb);
-  KL(softmax_bwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, t.dp, nb * H * S, S);                                 // ds
+  const int Sp = (S + 3) & ~3;                                                                                          // row stride of p / dp (block_fwd)
+  const long ss0 = (long)H * S * Sp, ss1 = (long)S * Sp;
+  auto padded = [](BG g) { g.a_padded = 1; return g; };
+  bgemm(st, false, true, BG{t.d, a.v, t.dp, nullptr, S, S, hd, D, D, Sp, (long)S * D, hd, (long)S * D, hd, ss0, ss1, 0, H, 1.f, 0}, nb);
+  bgemm(st, true, false, padded(BG{a.p, t.d, t.dv, nullptr, S, hd, S, Sp, D, D, ss0, ss1, (long)S * D, hd, (long)S * D, hd, 0, H, 1.f, 0}), nb);
+  KL(softmax_bwd_kernel, dim3((nb * H * S + 3) / 4), dim3(256), a.p, t.dp, nb * H * S, S, Sp);                             // ds
   const float sc = 1.f / sqrtf((float)hd);
-  bgemm(st, false, false, BG{t.dp, a.k, t.dq, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);   // dq = ds k / sqrt(hd)
-  bgemm(st, true, false, BG{t.dp, a.q, t.dk, nullptr, S, hd, S, S, D, D, (long)H * S * S, (long)S * S, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}, nb);    // dk = ds^T q / sqrt(hd)
+  bgemm(st, false, false, padded(BG{t.dp, a.k, t.dq, nullptr, S, hd, S, Sp, D, D, ss0, ss1, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}), nb);   // dq = ds k / sqrt(hd)
+  bgemm(st, true, false, padded(BG{t.dp, a.q, t.dk, nullptr, S, hd, S, Sp, D, D, ss0, ss1, (long)S * D, hd, (long)S * D, hd, 0, H, sc, 0}), nb);    // dk = ds^T q / sqrt(hd)
   const float* h = a.h ? a.h : t.h;
   if (!a.h) KL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), a.x_in, t.h, a.mean0, a.rstd0, w.l0s, w.l0b, ws, rows, S, D);      // recompute h
   const float* dqkv[3] = {t.dq, t.dk, t.dv};
@@ -1224,7 +1238,7 @@ static Plan make_plan(const Geom& g, int B, bool enc, float* base) {
   auto take = [&](long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
   auto take_blk = [&](long nb, long s, long d, long h, long f, bool ls) {
     BlkBuf b; b.x_in = take(nb * s * d); b.mean0 = take(nb * s); b.rstd0 = take(nb * s); b.q = take(nb * s * d); b.k = take(nb * s * d);
-    b.v = take(nb * s * d); b.p = take(nb * h * s * s); b.o = take(nb * s * d); b.x_mid = take(nb * s * d); b.mean1 = take(nb * s);
+    b.v = take(nb * s * d); b.p = take(nb * h * s * ((s + 3) & ~3L)); b.o = take(nb * s * d); b.x_mid = take(nb * s * d); b.mean1 = take(nb * s);
     b.rstd1 = take(nb * s); b.u = take(nb * s * f);
     b.y1 = ls ? take(nb * s * d) : nullptr; b.y2 = ls ? take(nb * s * d) : nullptr;
     // 288 GB of HBM: the LayerNorm and GELU outputs are kept (B = 32 with the encoder trained: 1.8 GB) instead of recomputed
@@ -1247,7 +1261,7 @@ static Plan make_plan(const Geom& g, int B, bool enc, float* base) {
   }
   // temporaries are used by one transformer at a time: size them for the largest
   auto mx = [&](long a, long b, long c) { c = enc ? c : 0; return a > b ? (a > c ? a : c) : (b > c ? b : c); };
-  const long rd = mx(B * S * D, B * Sc * C, B * Se * E), rf = mx(B * S * F, B * Sc * Fc, B * Se * Fe), hss = mx(B * H * S * S, B * Hc * Sc * Sc, B * He * Se * Se);
+  const long rd = mx(B * S * D, B * Sc * C, B * Se * E), rf = mx(B * S * F, B * Sc * Fc, B * Se * Fe), hss = mx(B * H * S * ((S + 3) & ~3L), B * Hc * Sc * ((Sc + 3) & ~3L), B * He * Se * ((Se + 3) & ~3L));
   pl.t.h = take(rd); pl.t.g = take(rf); pl.t.d = take(rf); pl.t.dq = take(rd); pl.t.dk = take(rd); pl.t.dv = take(rd); pl.t.dp = take(hss);
   pl.t.y = take(rd);
   pl.cmean = take(B); pl.crstd = take(B); pl.ctx = take(B * C); pl.dctx = take(B * C); pl.ctxn = take(B * C);
