@@ -24,6 +24,7 @@ struct BG {
                               //    depends on the order of the atomic adds in its last bits)
   int a_padded = 0;           // 1: every row of A is followed by zeros up to a multiple of 4 elements inside lda (the attention
                               //    matrices, row stride S rounded up): float4 staging may run over the row's end
+  long sBias1 = 0;            // bias stride of the inner batch index b1
 };
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0);
 
