@@ -59,7 +59,7 @@ struct hvla_ctx {
   DevBuf enc16, encd16, encf32;  // encoder matrices (16-bit), their rounding residues x 4096 (16-bit) and vectors (f32)
   EncWeights encw{};
   // workspaces (sized for cfg.max_batch)
-  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_corr, ws_abar, tokens, flags;
+  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_corr, ws_abar, ws_lncnt, tokens, flags;
   Profiler prof;
   float *amap_dino = nullptr, *amap_head = nullptr;     // hvla_set_attention_outputs: caller-owned device buffers (opt-in)
   // cfg.streams == 2: helper stream and fork / join events of hvla_step
@@ -157,7 +157,9 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   A(ctx->ws_g, gbytes); A(ctx->tokens, Bm * P * E * 4); A(ctx->flags, 64 * sizeof(int));
   A(ctx->ws_corr, 2 * Bm * (F > 3 * E ? F : 3 * E) * 4);      // two rows per image (upper / lower half): encoder.hip GemmArgs::corr
   A(ctx->ws_abar, 2 * Bm * (F > E ? F : E) * 2);
+  A(ctx->ws_lncnt, (Bm + 4) * 4 + 64);                          // tickets of the LayerNorm tails, one per image (16-byte multiples per half batch)
   if (e != hipSuccess) return HVLA_E_ARENA_FULL;
+  if (hipMemset(ctx->ws_lncnt.p, 0, ctx->ws_lncnt.bytes) != hipSuccess) return HVLA_E_HIP;
   if (c->streams == 2) {
     if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -477,6 +479,7 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
                   ctx->ws_corr.as<float>() + (size_t)2 * b0 * (F > 3 * E ? F : 3 * E),
                   static_cast<char*>(ctx->ws_abar.p) + (size_t)2 * b0 * (F > E ? F : E) * 2};
   if (ctx->amap_dino) ws.amap = ctx->amap_dino + (size_t)b0 * g.enc_layers * g.enc_heads * g.P();
+  if (ctx->cfg.layernorm_tail) ws.ln_cnt = ctx->ws_lncnt.as<uint32_t>() + (size_t)((b0 + 3) / 4 * 4);   // (a second half starts on a 16-byte boundary)
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
                              &ctx->prof, keep_cls));
@@ -513,6 +516,7 @@ int hvla_encode_audit(hvla_ctx* ctx, const uint8_t* images, int32_t B, float* ma
   const size_t F = g.enc_mlp, E = g.E;
   EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p, ctx->ws_corr.as<float>(), ctx->ws_abar.p};
   (void)F; (void)E;
+  if (ctx->cfg.layernorm_tail) ws.ln_cnt = ctx->ws_lncnt.as<uint32_t>();
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images, ctx->tokens.as<float>(), B, st, nullptr, false, slots));
   uint32_t h[8];
   HIPCHK(ctx, hipMemcpyAsync(h, slots, sizeof h, hipMemcpyDeviceToHost, st));
@@ -937,6 +941,12 @@ int hvla_debug_train_gemm_exact(int on) {
 }
 // shader-clock stamps of the last context-encoder launch (workgroup 0): see hypernet.hip CTX_STAMP
 int hvla_debug_ctx_stamps(unsigned long long* out) { return debug_ctx_stamps(out) == hipSuccess ? HVLA_OK : HVLA_E_HIP; }
+int hvla_debug_lnt_stats(hvla_ctx* ctx, unsigned long long* out, int reset) {
+  if (!ctx) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, debug_lnt_stats(out, reset));
+  return HVLA_OK;
+}
 #endif  // HVLA_BENCH_HOOKS
 
 int hvla_selftest(hvla_ctx* ctx, void* stream) {

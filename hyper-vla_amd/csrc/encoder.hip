@@ -109,6 +109,17 @@ struct GemmArgs {
   // GEMM's contiguous rows: 0, 256); nbm tile rows, every tile full
   int tile_row0 = 0, tile_stride = 256, nbm = 0;
   void* colmean = nullptr;       // GELU, image-aligned tiles only: [B][2][N] 16-bit mean over each wave row's 128 rows of its rounded outputs
+  // gemm256p_kernel<..., LNT = true> (RES / PATCH on image-aligned tiles): the LayerNorm that follows this GEMM as its TAIL.
+  // out is the f32 residual stream x [B*S][N] (N = E); its stores go through to memory (sc1), every tile draws a ticket
+  // from ln_cnt[image], and the workgroup that draws the image's last one normalises the image's S rows -> ln_out (16-bit)
+  // and writes the two mean rows -> ln_abar (nullable), with ln_row()'s arithmetic and layernorm_img_kernel's order of
+  // additions: the same bits as the stand-alone LayerNorm launch it replaces.
+  void* ln_out = nullptr;        // 16-bit [B*S][N]
+  const float* ln_scale = nullptr;
+  const float* ln_bias = nullptr;
+  void* ln_abar = nullptr;       // 16-bit [B][2][N]
+  uint32_t* ln_cnt = nullptr;    // [B] tickets, zero between launches (the last arriver puts the zero back)
+  uint32_t out_bytes = 0;        // size of `out` in bytes (buffer descriptor of the write-through stores)
 };
 
 // Row-major epilogue shared by the three GEMM kernels.  They run the MFMA with the activation fragment as the first
@@ -132,7 +143,11 @@ __device__ __forceinline__ f32x4 corr_value(f32x4 acc, float b) {
 // CS (GELU, FULL only): also returns in cs this lane's sums over its rows of the ROUNDED outputs of its four columns,
 // accumulated in the operand type itself (fp16: two v_pk_add_f16 per row instead of four converts and four adds; 32 values
 // per lane, and the mean row only needs a few per cent: colmean_kernel restates exactly this arithmetic).
-template <typename Op, int EPI, int MT, bool FULL, bool ROWBIAS, bool CS = false>
+// WT (RES / PATCH): the f32 rows are stored write-through (buffer stores with sc1: they reach the memory side, no dirty line
+// stays in this XCD's L2), so that another workgroup may read them inside this launch behind the stores' vmcnt(0), a
+// ticket and an agent-scope acquire (the LayerNorm tail of gemm256p_kernel) without a release fence, which would write
+// back the whole L2 once per tile (measured in round 2: 830 us per launch).
+template <typename Op, int EPI, int MT, bool FULL, bool ROWBIAS, bool CS = false, bool WT = false>
 __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
                                                         int fr, int fq, const f32x4* pre_b4, const f32x4* pre_l4,
                                                         typename Op::x4* cs = nullptr,
@@ -145,6 +160,12 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
   f32x4 l4 = f32x4{1.f, 1.f, 1.f, 1.f};
   if constexpr (EPI == EPI_RES) l4 = pre_l4 ? *pre_l4 : *reinterpret_cast<const f32x4*>(g.aux + n);
   const float q = EPI == EPI_PATCH ? g.qscale : ((EPI == EPI_QKV && n_base < g.qcols) ? g.qscale : 1.f);
+  __amdgpu_buffer_rsrc_t wt_rsrc;
+  if constexpr (WT) wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)g.out_bytes, 0x00020000);
+  auto store_f32x4 = [&](uint32_t elem_off, f32x4 v) {
+    if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), wt_rsrc, (int)(elem_off * 4u), 0, 16);   // aux 16 = sc1
+    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + elem_off) = v;
+  };
   constexpr int RB = MT < 2 ? 1 : (EPI == EPI_RES && MT >= 4 ? 4 : 2);   // m-tiles per batch: residual loads of a batch are issued together
 #pragma unroll
   for (int mp = 0; mp < MT; mp += RB) {
@@ -210,14 +231,14 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
           f32x4 x = xin[u][r];
 #pragma unroll
           for (int c = 0; c < 4; ++c) x[c] = fmaf(t[c][r], l4[c], x[c]);
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + off[u][r]) = x;
+          store_f32x4(off[u][r], x);
         } else if constexpr (EPI == EPI_CORR) {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + off[u][r]) = f32x4{t[0][r], t[1][r], t[2][r], t[3][r]};
         } else {
           f32x4 x = xin[u][r];
 #pragma unroll
           for (int c = 0; c < 4; ++c) x[c] += t[c][r];
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + off[u][r]) = x;
+          store_f32x4(off[u][r], x);
         }
       }
     }
@@ -735,6 +756,200 @@ __global__ __launch_bounds__(256) void gemm64c32_kernel(GemmArgs g) {
   }
 }
 
+// 16-lane row reductions by DPP (quad swaps, then the half-row and row mirrors) and an SGPR broadcast of one lane
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  return fmaxf(v, dpp_mov<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  return v + dpp_mov<0x140>(v);
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// sum over all 64 lanes, the same value in every lane: DPP inside the four 16-lane rows, then the four row sums through
+// SGPRs -- about a hundred cycles of dependent latency instead of six ds_bpermute round trips
+__device__ __forceinline__ float wave64_sum(float v) {
+  const float t = row16_sum(v);
+  return (lane_bcast(t, 0) + lane_bcast(t, 16)) + (lane_bcast(t, 32) + lane_bcast(t, 48));
+}
+
+constexpr int LNW = 16;
+// one row: statistics (f32, two passes over the registers), the f32 outputs y (what the column sums add) and the 16-bit store.
+// Shared by the one-workgroup-per-image kernel and the split form below, so that a row and its contribution to the mean row
+// are the same bits in both.
+// NCH: 64-lane chunks of four columns a row is held in (4 covers E <= 1024; the LayerNorm tail of gemm256p_kernel uses 3 for
+// E <= 768 to have registers for more rows in flight: an absent chunk only ever contributed + 0.0f).
+// FULLCH: n4 == 64 * NCH, every chunk is full -- no per-chunk predicate (the predicates are divergent branches to the compiler,
+// and behind their joins it waits vmcnt(0) for every load in flight: the tail's row prefetch needs the branch-free form).
+template <typename Op, int NCH = 4, bool FULLCH = false, typename OutPtr = typename Op::elem*>
+__device__ __forceinline__ void ln_row(const f32x4 (&cur)[NCH], const f32x4 (&s4)[NCH], const f32x4 (&b4)[NCH], int n4, float invE, int lane,
+                                       OutPtr orow, f32x4 (&y)[NCH]) {     // invE = 1.f / E (one multiply instead of an IEEE division per statistic)
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
+  sum = wave64_sum(sum);
+  const float mean = sum * invE;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (FULLCH || lane + 64 * i < n4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = cur[i][j] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  sq = wave64_sum(sq);
+  const float rstd = rsqrtf(sq * invE + 1e-6f);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int col = lane + 64 * i;
+    y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (FULLCH || col < n4) {
+      typename Op::x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[i][j] = (cur[i][j] - mean) * rstd * s4[i][j] + b4[i][j];
+        o[j] = (typename Op::elem)y[i][j];
+      }
+      if constexpr (std::is_same<OutPtr, typename Op::elem*>::value) reinterpret_cast<typename Op::x4*>(orow)[col] = o;
+      else ((__attribute__((address_space(1))) typename Op::x4*)orow)[col] = o;
+    }
+  }
+}
+
+
+// The LayerNorm that follows a residual GEMM (norm1 / norm2) as a TAIL JOB of gemm256p_kernel: run by a workgroup that has
+// claimed image `img` after every column tile of the image's 256 patch rows has stored its part of x write-through and
+// drained (the CLS row was finished by an earlier launch).  Eight waves; wave w plays the "waves" w and w + 8 of
+// layernorm_img_kernel (rows w, w + 16, ... and w + 8, w + 24, ...: separate column sums A / B), ln_row() is the same function,
+// and the sixteen partial column sums are added in that kernel's order -- so the 16-bit rows and the two mean rows are the
+// bits the stand-alone launch would have written.  D rows per wave are in flight (the reads come from the memory side, ~2 us
+// away under load: 8 waves x 8 rows x 3 KB); the two rows of a pair (one A, one B) are normalised in ONE basic block so that
+// the scheduler interleaves their dependent reduction chains (the tail is bound by VALU issue, two waves per SIMD).
+// S = 257 (image-aligned tiles only exist for 256 patches).  lds: LNT_RED bytes of scratch for the sums.
+constexpr int LNT_CW = 192;                    // float4 columns per pass of the mean-row sums: [16][LNT_CW] float4 = 48 KB
+constexpr int LNT_RED = 16 * LNT_CW * 16;
+// Inlined.  (As a real call -- noinline, a register allocation of its own -- the tail was 3 us slower per job: its callee-saved
+// registers go to scratch and back on every call, 188 scratch operations; inlined with FOUR rows per block the one allocation
+// problem of the whole kernel answered with 49 spills inside the K loops.  Two rows per block and an opaque copy of the thread id
+// at the call site keep the K loops clean: tools/kernel_resources.sh.)
+typedef __attribute__((address_space(3))) char lds_char;
+template <typename Op, int NCH, bool FULLCH>
+__device__ __forceinline__ void ln_tail(const float* x, typename Op::elem* out, const float* ln_scale, const float* ln_bias,
+                                                 typename Op::elem* abar, int S, int E, int hsplit, lds_char* lds, int wave, int tid) {
+  using T = typename Op::elem;
+  // a callee's pointer arguments are generic to the compiler (flat_load / flat_store, counted on vmcnt AND lgkmcnt: every wait
+  // becomes a full drain); they are global memory
+  typedef const __attribute__((address_space(1))) f32x4 g_cf32x4;
+  typedef __attribute__((address_space(1))) typename Op::x4 g_x4;
+  typedef __attribute__((address_space(1))) typename Op::elem g_elem;
+  const int lane = tid & 63;
+  const int n4 = E / 4;
+  const float invE = 1.f / (float)E;
+  f32x4 s4[NCH], b4[NCH], csA0[NCH], csA1[NCH], csB0[NCH], csB1[NCH];
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int col = lane + 64 * i;
+    csA0[i] = csA1[i] = csB0[i] = csB1[i] = z4;
+    s4[i] = (FULLCH || col < n4) ? ((g_cf32x4*)ln_scale)[col] : z4;
+    b4[i] = (FULLCH || col < n4) ? ((g_cf32x4*)ln_bias)[col] : z4;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(s4[i]), "+v"(b4[i]));      // waited for here, not inside the row loop
+  constexpr int D = NCH <= 3 ? 8 : 4;          // rows in flight per wave (even: row d of a group is A for even d, B for odd d)
+  f32x4 buf[D][NCH];
+  auto load = [&](f32x4 (&v)[NCH], int row) {
+    g_cf32x4* xr = (g_cf32x4*)(x + (size_t)(row < S ? row : S - 1) * E);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int col = lane + 64 * i;
+      if constexpr (FULLCH) v[i] = xr[col];
+      else {                                   // the load itself is unconditional (a valid address), the zero a select
+        const f32x4 t = xr[col < n4 ? col : n4 - 1];
+        v[i] = col < n4 ? t : z4;
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) load(buf[d], wave + 8 * d);
+  constexpr int G = 2;                         // rows normalised per basic block: their reduction chains are independent, the scheduler interleaves them
+  static_assert(D % G == 0 && G % 2 == 0, "a group is whole A / B pairs of the rows in flight");
+  for (int i0 = 0; i0 < 32; i0 += D) {         // rows wave + 8 i, i < 32: rows 0 .. 255
+#pragma unroll
+    for (int d0 = 0; d0 < D; d0 += G) {
+      f32x4 y[G][NCH];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int row = wave + 8 * (i0 + d0 + u);
+        ln_row<Op, NCH, FULLCH, g_elem*>(buf[d0 + u], s4, b4, n4, invE, lane, (g_elem*)(out + (size_t)row * E), y[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) load(buf[d0 + u], wave + 8 * (i0 + d0 + u + D));   // (past the end: the last row again, unused)
+#pragma unroll
+      for (int u = 0; u < G; ++u) {            // ascending rows per virtual wave: A = even u, B = odd u
+        const int row = wave + 8 * (i0 + d0 + u);
+        if (row < hsplit) {                    // wave-uniform
+#pragma unroll
+          for (int i = 0; i < NCH; ++i)
+            if (u & 1) csB0[i] += y[u][i]; else csA0[i] += y[u][i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < NCH; ++i)
+            if (u & 1) csB1[i] += y[u][i]; else csA1[i] += y[u][i];
+        }
+      }
+    }
+  }
+  if (wave == 0) {                             // row 256 = the last row of "wave 0" (buf[0] holds it: row 0 + 8 * 32)
+    f32x4 y[NCH];
+    ln_row<Op, NCH, FULLCH, g_elem*>(buf[0], s4, b4, n4, invE, lane, (g_elem*)(out + (size_t)(S - 1) * E), y);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) csA1[i] += y[i];
+  }
+  if (!abar) return;                           // (uniform over the workgroup)
+  typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+  lds_f32x4* red = reinterpret_cast<lds_f32x4*>(lds);   // [16][LNT_CW]
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    for (int c0 = 0; c0 < n4; c0 += LNT_CW) {  // one pass at E <= 768
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int col = lane + 64 * i - c0;
+        if (col >= 0 && col < LNT_CW && col + c0 < n4) {
+          red[wave * LNT_CW + col] = hf ? csA1[i] : csA0[i];
+          red[(wave + 8) * LNT_CW + col] = hf ? csB1[i] : csB0[i];
+        }
+      }
+      __syncthreads();
+      if (tid < LNT_CW && c0 + tid < n4) {
+        f32x4 t = red[tid];
+#pragma unroll
+        for (int w = 1; w < LNW; ++w) t += red[w * LNT_CW + tid];
+        const float inv = 1.f / (float)(hf ? S - hsplit : hsplit);
+        typename Op::x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (T)(t[j] * inv);
+        ((g_x4*)(abar + (size_t)hf * E))[c0 + tid] = o;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // gemm256p_kernel -- the production GEMM.  256x256x64 block tiles, 8 waves (2 along M x 4 along N, 128x64 each), operands
 // staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction).  The LDS
@@ -761,10 +976,22 @@ constexpr int PRO_DMA = 12, PRO_DMA_KT0 = 8;        // LDS-DMA instructions per 
 // loads, stores and DMA together and retires in order): MT = 8 m-tiles x 4 rows of stores, plus as many residual loads.
 template <int EPI> struct EpiVmem { static constexpr int min_ops = (EPI == EPI_RES || EPI == EPI_PATCH) ? 64 : 32; };
 
-template <typename Op, int EPI, bool PERSIST>
+// LNT (RES / PATCH, image-aligned tiles): the LayerNorm behind this GEMM runs as its tail -- GemmArgs::ln_*, ln_tail().  The
+// launch then asks for 160 KB of LDS: the tail's scratch starts at LNT_SCRATCH = the W half of buffer 1, which the next tile's
+// prologue DMA (already in flight during the epilogue) does not touch, and runs into the 32 KB behind the buffers; the last
+// 16 bytes are the word through which wave 0 tells the workgroup which image it claimed.
+#ifdef HVLA_BENCH_HOOKS
+// libhvla_bench.so (tools/lnt_stats.py): per workgroup id, summed over the launches since the last reset:
+// [0] tail jobs done, [1] shader-clock ticks inside tail jobs, [2] ticks from the drain to "job known", [3] launches
+__device__ unsigned long long g_lnt_dbg[4][256];
+#endif
+constexpr int LNT_SCRATCH = 98304, LNT_LDS = 163840, LNT_CTRL = LNT_LDS - 16;
+static_assert(LNT_SCRATCH + LNT_RED <= LNT_CTRL, "the tail's scratch ends below the control word");
+template <typename Op, int EPI, bool PERSIST, bool LNT = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   using T = typename Op::elem;
   using X8 = typename Op::x8;
+  static_assert(!LNT || EPI == EPI_RES || EPI == EPI_PATCH, "the LayerNorm tail follows a GEMM that writes the residual stream");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 buffers x (A 32 KB | W 32 KB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -905,6 +1132,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
+  if constexpr (LNT) {            // tail jobs this workgroup has done: a word of LDS, not a register across the K loops (read
+    if (tid == 0) reinterpret_cast<volatile int*>(smem + LNT_CTRL)[1] = 0;    // by wave 0 behind dozens of barriers)
+  }
   while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -928,9 +1158,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     const bool wvalid = cn0 + wn * 64 < g.N;          // (wave-uniform) this wave's 64 columns exist
     f32x4 pb4 = f32x4{0.f, 0.f, 0.f, 0.f}, pl4 = pb4;
     if (wvalid) {
-      pb4 = *reinterpret_cast<const f32x4*>(brow + cn0 + wn * 64 + 4 * fr);
+      const uint32_t vcol = (uint32_t)(cn0 + wn * 64 + 4 * fr);     // 32-bit lane offset on a uniform base: no 64-bit lane address kept across the K loop
+      pb4 = *reinterpret_cast<const f32x4*>(brow + vcol);
       pl4 = pb4;
-      if constexpr (EPI == EPI_RES) pl4 = *reinterpret_cast<const f32x4*>(g.aux + cn0 + wn * 64 + 4 * fr);
+      if constexpr (EPI == EPI_RES) pl4 = *reinterpret_cast<const f32x4*>(g.aux + vcol);
     }
     asm volatile("" : "+v"(pb4), "+v"(pl4));
     if constexpr (PERSIST) {
@@ -971,8 +1202,152 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       } else {
         gemm_epilogue_rows_impl<Op, EPI, 8, true, false>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
       }
+    } else if constexpr (LNT) {
+      gemm_epilogue_rows_impl<Op, EPI, 8, true, false, false, true>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
     } else {
       gemm_epilogue_rows_impl<Op, EPI, 8, true, false>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
+    }
+    if constexpr (LNT) {
+      // ---- LayerNorm tail jobs.  Guide 6 G16 / "in-launch split-K reduction" in its write-through form: every wave's stores
+      // of x have reached the memory side (vmcnt(0); also: the next tile's prologue DMA has landed), the workgroup's barrier,
+      // ONE lane adds the image's ticket (relaxed, agent scope).  ln_cnt[image]: bits 0-7 count the arrived column tiles; all
+      // nbn arrived = every tile of the image is in memory and the image belongs to its last arriver, which either normalises
+      // it at once or PUBLISHES it (LNT_FREE) for another workgroup to claim (compare-and-swap back to nbn); 0 again when its
+      // tail is done.  Whoever normalises an image acquires first (buffer_inv sc1: this CU's L1; its wait is in front of the
+      // barrier that lets the other waves read) and reads the rows with plain loads.  Which workgroup, CU or XCD ran the image's
+      // tiles, and which one normalises it, does not matter for the result.
+      // WHO does it is a matter of balance only.  A workgroup has nbn tiles of 30-90 us and a tail costs ~20 us: if the last
+      // arriver always did the tail, the workgroups delayed by one tail would be the last arrivers of the next round too and a
+      // few of them would do three.  So: after a tile that is not its last a workgroup takes ONE job and only if it has not
+      // done one yet (its own image if it completed it, else a published one of its XCD's id range); a last arriver that may
+      // not take its image publishes it; after its last tile a workgroup takes jobs until nothing is published anywhere.
+      // Nobody waits for anybody, and a published image is always found: at the latest by the final sweep of the workgroup
+      // that published it.  The fast path (last arriver, eligible) is ONE atomic round trip; the first 64 words of the sweep
+      // are requested together with the ticket.
+      constexpr uint32_t LNT_FREE = 0x100u;
+#ifdef HVLA_BENCH_HOOKS
+      const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      volatile int* lctrl = reinterpret_cast<volatile int*>(smem + LNT_CTRL);
+      const bool final_tile = !more;
+      // the images that have a tile in the id range of this workgroup's XCD label (blockIdx % 8; tile_origin: with GN == nbn
+      // -- true for N <= 1024 -- an image's tiles are nbn consecutive ids).  Computed here, not kept across the K loops.
+      int img_lo, img_hi;
+      {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = (int)blockIdx.x % 8;
+        const int b0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+        img_lo = b0 / nbn;
+        img_hi = cnt > 0 ? (b0 + cnt - 1) / nbn + 1 : img_lo;
+      }
+      const uint32_t w_free = (uint32_t)nbn | LNT_FREE;
+      auto claim = [&](int img) -> bool {               // wave 0; lane 0's compare-and-swap published -> owned, broadcast
+        uint32_t ok = 0;
+        if (lane == 0) {
+          uint32_t expect = w_free;
+          ok = __hip_atomic_compare_exchange_strong(g.ln_cnt + img, &expect, (uint32_t)nbn, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+        }
+        return __builtin_amdgcn_readfirstlane(ok) != 0;
+      };
+      auto peek = [&](int base, int hi) -> uint32_t {   // wave 0: lane l reads the word of image base + l
+        const int i = base + lane;
+        return i < hi ? __hip_atomic_load(g.ln_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      };
+      auto pick = [&](int base, uint32_t v) -> int {    // wave 0: claim one of the published images among 64 peeked words
+        unsigned long long m = __ballot(v == w_free);
+        while (m) {
+          const int img = base + __builtin_ctzll(m);
+          if (claim(img)) return img;
+          m &= m - 1;
+        }
+        return -1;
+      };
+      auto sweep = [&](int lo, int hi, int skip) -> int {   // wave 0: a published image in [lo, hi), claimed; -1 if none
+        for (int base = lo; base < hi; base += 64) {
+          if (base == skip) continue;                       // (already peeked)
+          const int j = pick(base, peek(base, hi));
+          if (j >= 0) return j;
+        }
+        return -1;
+      };
+      int tails_done = 0;
+      if (wave == 0) {
+        tails_done = __builtin_amdgcn_readfirstlane(lctrl[1]);
+        const bool elig = tails_done == 0 || final_tile;
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(g.ln_cnt + ctm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t v0 = 0;
+        if (elig) v0 = peek(img_lo, img_hi);                // requested before the ticket's answer is needed
+        const uint32_t arrived = (__builtin_amdgcn_readfirstlane(old) & 0xffu) + 1u;
+        int job = -1;
+        if (arrived == (uint32_t)nbn) {
+          if (elig) job = ctm;                              // the image is this workgroup's
+          else if (lane == 0) __hip_atomic_fetch_or(g.ln_cnt + ctm, LNT_FREE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (job < 0 && elig) {
+          job = pick(img_lo, v0);
+          if (job < 0) job = sweep(img_lo, img_hi, img_lo);
+          if (job < 0 && final_tile) job = sweep(0, nbm, -1);
+        }
+        if (job >= 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (lane == 0) *lctrl = job;
+      }
+      __syncthreads();
+      int job = *lctrl;
+      __syncthreads();                                    // (the word is read by every wave before wave 0 writes it again)
+#ifdef HVLA_BENCH_HOOKS
+      const unsigned long long dbg_t1 = __builtin_readcyclecounter();
+      if (tid == 0 && blockIdx.x < 256) {
+        atomicAdd(&g_lnt_dbg[2][blockIdx.x], dbg_t1 - dbg_t0);
+        if (final_tile) atomicAdd(&g_lnt_dbg[3][blockIdx.x], 1ull);
+      }
+#endif
+      while (job >= 0) {
+        {
+          const float* jx = reinterpret_cast<const float*>(g.out) + (size_t)job * g.S * g.N;
+          T* jout = reinterpret_cast<T*>(g.ln_out) + (size_t)job * g.S * g.N;
+          T* jabar = g.ln_abar ? reinterpret_cast<T*>(g.ln_abar) + (size_t)job * 2 * g.N : nullptr;
+          lds_char* jlds = (lds_char*)smem + LNT_SCRATCH;
+          // an opaque copy of the thread id: nothing the tail derives from it can be hoisted out of the tile loop (lane-constant
+          // addresses computed at kernel entry stay live through the K loops, which have no register to spare)
+          int tid_t = tid;
+          asm volatile("" : "+v"(tid_t));
+          if (g.N == 768) ln_tail<Op, 3, true>(jx, jout, g.ln_scale, g.ln_bias, jabar, g.S, g.N, g.hsplit, jlds, wave, tid_t);
+          else if (g.N == 1024) ln_tail<Op, 4, true>(jx, jout, g.ln_scale, g.ln_bias, jabar, g.S, g.N, g.hsplit, jlds, wave, tid_t);
+          else ln_tail<Op, 4, false>(jx, jout, g.ln_scale, g.ln_bias, jabar, g.S, g.N, g.hsplit, jlds, wave, tid_t);
+        }
+        ++tails_done;
+        __syncthreads();                                  // the scratch is free again (next job / next tile's W halves)
+#ifdef HVLA_BENCH_HOOKS
+        if (tid == 0 && blockIdx.x < 256) atomicAdd(&g_lnt_dbg[0][blockIdx.x], 1ull);
+#endif
+        if (wave == 0) {
+          if (lane == 0) __hip_atomic_store(g.ln_cnt + job, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+          int nj = -1;
+          if (final_tile) {
+            nj = sweep(img_lo, img_hi, -1);
+            if (nj < 0) nj = sweep(0, nbm, -1);
+            if (nj >= 0) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+          }
+          if (lane == 0) *lctrl = nj, lctrl[1] = tails_done;
+        }
+        __syncthreads();
+        job = *lctrl;
+        __syncthreads();
+      }
+#ifdef HVLA_BENCH_HOOKS
+      if (tid == 0 && blockIdx.x < 256) atomicAdd(&g_lnt_dbg[1][blockIdx.x], (unsigned long long)__builtin_readcyclecounter() - dbg_t1);
+#endif
+      if (!more) break;
+      continue;                                           // (the vmcnt(0) above covers the wait below)
     }
     if (!more) break;
     // K-tile 0 of the next tile must have landed: its PRO_DMA_KT0 instructions are the oldest of the PRO_DMA + (epilogue)
@@ -986,34 +1361,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
   }
 #undef HVLA_BAR
-}
-
-// 16-lane row reductions by DPP (quad swaps, then the half-row and row mirrors) and an SGPR broadcast of one lane
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x141>(v));
-  return fmaxf(v, dpp_mov<0x140>(v));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_mov<0xB1>(v);
-  v += dpp_mov<0x4E>(v);
-  v += dpp_mov<0x141>(v);
-  return v + dpp_mov<0x140>(v);
-}
-__device__ __forceinline__ float lane_bcast(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
-// sum over all 64 lanes, the same value in every lane: DPP inside the four 16-lane rows, then the four row sums through
-// SGPRs -- about a hundred cycles of dependent latency instead of six ds_bpermute round trips
-__device__ __forceinline__ float wave64_sum(float v) {
-  const float t = row16_sum(v);
-  return (lane_bcast(t, 0) + lane_bcast(t, 16)) + (lane_bcast(t, 32) + lane_bcast(t, 48));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1084,47 +1431,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // the running f32 sums of its columns, and the 16 waves are combined through LDS in wave order -- the mean row abar[b] comes
 // out of the same launch (no partial sums in memory, no second kernel), and the order of the additions depends on nothing
 // but the image.  A batch of 256 images is exactly one workgroup per CU.  E % 4 == 0, E <= 1024.
-constexpr int LNW = 16;
-// one row: statistics (f32, two passes over the registers), the f32 outputs y (what the column sums add) and the 16-bit store.
-// Shared by the one-workgroup-per-image kernel and the split form below, so that a row and its contribution to the mean row
-// are the same bits in both.
-template <typename Op>
-__device__ __forceinline__ void ln_row(const f32x4 (&cur)[4], const f32x4 (&s4)[4], const f32x4 (&b4)[4], int n4, int E, int lane,
-                                       typename Op::elem* __restrict__ orow, f32x4 (&y)[4]) {
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
-  sum = wave64_sum(sum);
-  const float mean = sum / E;
-  float sq = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (lane + 64 * i < n4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float d = cur[i][j] - mean;
-        sq += d * d;
-      }
-    }
-  }
-  sq = wave64_sum(sq);
-  const float rstd = rsqrtf(sq / E + 1e-6f);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int col = lane + 64 * i;
-    y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (col < n4) {
-      typename Op::x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        y[i][j] = (cur[i][j] - mean) * rstd * s4[i][j] + b4[i][j];
-        o[j] = (typename Op::elem)y[i][j];
-      }
-      reinterpret_cast<typename Op::x4*>(orow)[col] = o;
-    }
-  }
-}
-
 template <typename Op>
 __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
@@ -1161,7 +1467,7 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __
   for (int row = wave; row < S; row += LNW) {                        // wave-uniform
     load(nxt, row + LNW);
     f32x4 y[4];
-    ln_row<Op>(cur, s4, b4, n4, E, lane, out + ((size_t)b * S + row) * E, y);
+    ln_row<Op>(cur, s4, b4, n4, 1.f / (float)E, lane, out + ((size_t)b * S + row) * E, y);
     if (row < hsplit) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) cs[i] += y[i];
@@ -1222,7 +1528,7 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_split_kernel(const float* 
       const int col = lane + 64 * i;
       cur[i] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    ln_row<Op>(cur, s4, b4, n4, E, lane, out + ((size_t)b * S + row) * E, y);
+    ln_row<Op>(cur, s4, b4, n4, 1.f / (float)E, lane, out + ((size_t)b * S + row) * E, y);
     if (partial) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1659,6 +1965,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm256p_kernel<Op, EPI_GELU, false>)) SETA((gemm256p_kernel<Op, EPI_RES, false>))
     SETA((gemm256p_kernel<Op, EPI_PATCH, true>)) SETA((gemm256p_kernel<Op, EPI_QKV, true>))
     SETA((gemm256p_kernel<Op, EPI_GELU, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true>))
+    SETA((gemm256p_kernel<Op, EPI_PATCH, false, true>)) SETA((gemm256p_kernel<Op, EPI_RES, false, true>))
+    SETA((gemm256p_kernel<Op, EPI_PATCH, true, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true, true>))
     SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
     SETA((gemm64_kernel<Op, EPI_RES>)) SETA((gemm64_kernel<Op, EPI_CORR>))
     SETA((gemm64_kernel<Op, EPI_QKV, 4>)) SETA((gemm64_kernel<Op, EPI_GELU, 4>)) SETA((gemm64_kernel<Op, EPI_RES, 4>))
@@ -1681,9 +1989,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   //  * otherwise a corr-only gemm64_kernel launch, then gemm64_kernel (<= 2047 rows) or gemm_kernel (128x128 tiles) over all rows, bias row
   //    looked up per row.
   // Returns whether the image-aligned form ran (then a GELU epilogue writes the mean row of its output itself).
+  // ln_s / ln_b (RES only): scale and bias of the LayerNorm that follows this GEMM; the image-aligned form runs it as its tail
+  // (GemmArgs::ln_*) and sets ln_fused, otherwise the caller launches it.
+  bool ln_fused = false;
+  const bool can_fuse_ln = ws.ln_cnt != nullptr && (size_t)M * E * 4 < (1ull << 32) && E <= 1024;
   auto gemm = [&](auto epic, const void* A, const void* Wt, const void* dW, int N, int K, const float* bias, const float* aux,
-                  void* out, int qcols, int cat, void* colmean = nullptr) -> bool {
+                  void* out, int qcols, int cat, void* colmean = nullptr, const float* ln_s = nullptr, const float* ln_b = nullptr) -> bool {
     constexpr int EPI = decltype(epic)::value;
+    ln_fused = false;
     GemmArgs a{A, Wt, M, N, K, bias, aux, out, P, S, qcols, qcols ? 0.125f * 1.4426950408889634f : 1.f / 256.f};   // q: 1/sqrt(64) and exp -> exp2
     a.hsplit = hsplit;
     const bool fits32 = (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
@@ -1712,6 +2025,17 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       a.nbm = B; a.tile_row0 = 1; a.tile_stride = S; a.colmean = colmean;
       const size_t lds = 131072;
       pf.begin(cat, st);
+      if constexpr (EPI == EPI_RES) {
+        if (ln_s && can_fuse_ln) {                     // the LayerNorm behind this GEMM as its tail
+          a.ln_out = ws.h; a.ln_scale = ln_s; a.ln_bias = ln_b; a.ln_abar = comp ? ws.abar : nullptr; a.ln_cnt = ws.ln_cnt;
+          a.out_bytes = (uint32_t)((size_t)M * N * 4);
+          if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true, true>), dim3(ncu), dim3(512), LNT_LDS, st, a);
+          else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false, true>), dim3(B * nbn), dim3(512), LNT_LDS, st, a);
+          pf.end(cat, st);
+          ln_fused = true;
+          return true;
+        }
+      }
       if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), lds, st, a);
       else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), lds, st, a);
       pf.end(cat, st);
@@ -1772,6 +2096,9 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (!audit) return;
     hipLaunchKernelGGL((absmax_kernel<T>), dim3(1024), dim3(256), 0, st, reinterpret_cast<const T*>(buf), n / 8, audit + 2 * site);
   };
+  // tickets of the LayerNorm tails: zero before the first launch of every call (the last arriver of an image puts the zero
+  // back, so this only matters after a launch that did not finish; a memset node when the call is captured)
+  if (can_fuse_ln && P == HBM_ && M > G64_MAXM && (e = hipMemsetAsync(ws.ln_cnt, 0, (size_t)((B * 4 + 15) / 16 * 16), st)) != hipSuccess) return e;
   using EQ = std::integral_constant<int, EPI_QKV>;
   using EG = std::integral_constant<int, EPI_GELU>;
   using ER = std::integral_constant<int, EPI_RES>;
@@ -1790,7 +2117,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (Mp % HBM_ == 0 && E % SBN == 0 && E >= HBN_ && Mp > G64_MAXM && fits32) {
       a.nbm = Mp / HBM_; a.tile_row0 = 0; a.tile_stride = HBM_;
       const int nbn = (E + HBN_ - 1) / HBN_;
-      if ((a.nbm * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true>), dim3(ncu), dim3(512), 131072, st, a);
+      if (P == HBM_ && can_fuse_ln && g.enc_layers > 0) {   // a tile row is an image: norm1 of layer 0 as the tail (the CLS rows are written above)
+        a.hsplit = hsplit;
+        a.ln_out = ws.h; a.ln_scale = w.layer[0].ln1_s; a.ln_bias = w.layer[0].ln1_b; a.ln_abar = comp ? ws.abar : nullptr;
+        a.ln_cnt = ws.ln_cnt; a.out_bytes = (uint32_t)((size_t)M * E * 4);
+        if ((a.nbm * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true, true>), dim3(ncu), dim3(512), LNT_LDS, st, a);
+        else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false, true>), dim3(a.nbm * nbn), dim3(512), LNT_LDS, st, a);
+        ln_fused = true;
+      } else if ((a.nbm * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true>), dim3(ncu), dim3(512), 131072, st, a);
       else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false>), dim3(a.nbm * nbn), dim3(512), 131072, st, a);
     } else if (Mp <= G64_MAXM && fits32 && E % SBN == 0) {
       hipLaunchKernelGGL((gemm64_kernel<Op, EPI_PATCH>), dim3(((Mp + SBM - 1) / SBM) * (E / SBN)), dim3(256), SNS * 16384, st, a);
@@ -1804,9 +2138,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                            (size_t)(KT - 1) * 64 * sizeof(float);
   for (int l = 0; l < g.enc_layers; ++l) {
     const EncLayerW& L = w.layer[l];
-    pf.begin(1, st);
-    layernorm(L.ln1_s, L.ln1_b);
-    pf.end(1, st);
+    if (!ln_fused) {                    // norm1: otherwise done as the tail of the previous layer's fc2 / of the patch embedding
+      pf.begin(1, st);
+      layernorm(L.ln1_s, L.ln1_b);
+      pf.end(1, st);
+    }
     audit_of(ws.h, (size_t)M * E, 0);
     gemm(EQ{}, ws.h, L.wqkv, L.dqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, 2);                       // the LayerNorm wrote the mean row itself
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
@@ -1821,15 +2157,18 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                          nullptr, 0);
     pf.end(3, st);
     audit_of(ws.h, (size_t)M * E, 2);
-    gemm(ER{}, ws.h, L.wo, L.dwo, E, E, L.bo, L.ls1, ws.x, 0, 4);                     // the attention kernel wrote the mean row itself
-    pf.begin(1, st);
-    layernorm(L.ln2_s, L.ln2_b);
-    pf.end(1, st);
+    gemm(ER{}, ws.h, L.wo, L.dwo, E, E, L.bo, L.ls1, ws.x, 0, 4, nullptr, L.ln2_s, L.ln2_b);   // the attention kernel wrote the mean row itself; norm2 as the tail
+    if (!ln_fused) {
+      pf.begin(1, st);
+      layernorm(L.ln2_s, L.ln2_b);
+      pf.end(1, st);
+    }
     audit_of(ws.h, (size_t)M * E, 0);
     const bool summed = gemm(EG{}, ws.h, L.w1, L.dw1, F, E, L.b1, nullptr, ws.g, 0, 5, comp ? ws.abar : nullptr);
     audit_of(ws.g, (size_t)M * F, 3);
     if (!summed) colmean_of(ws.g, F);                                                 // aligned tiles: the GELU epilogue wrote the mean row
-    gemm(ER{}, ws.g, L.w2, L.dw2, E, F, L.b2, L.ls2, ws.x, 0, 6);
+    if (l + 1 < g.enc_layers) gemm(ER{}, ws.g, L.w2, L.dw2, E, F, L.b2, L.ls2, ws.x, 0, 6, nullptr, w.layer[l + 1].ln1_s, w.layer[l + 1].ln1_b);   // the next layer's norm1 as the tail
+    else gemm(ER{}, ws.g, L.w2, L.dw2, E, F, L.b2, L.ls2, ws.x, 0, 6);
   }
   pf.begin(1, st);
   if (keep_cls)
@@ -1841,6 +2180,15 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
 }
 
 #ifdef HVLA_BENCH_HOOKS
+hipError_t debug_lnt_stats(unsigned long long* out, int reset) {   // out: host [4][256]
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess && out) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lnt_dbg), sizeof(unsigned long long) * 4 * 256);
+  if (e == hipSuccess && reset) {
+    static unsigned long long zero[4][256];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_lnt_dbg), zero, sizeof zero);
+  }
+  return e;
+}
 // diagnostics, libhvla_bench.so only (tools/gemm_bench.py): time `iters` launches of one encoder GEMM shape on workspace buffers (contents
 // irrelevant).  variant 0: gemm_kernel (128x128), 1: gemm64_kernel, 2: gemm256p_kernel one workgroup per tile,
 // 3: gemm256p_kernel persistent.  M is rounded down to whole 256-row tiles for variants 2 and 3.

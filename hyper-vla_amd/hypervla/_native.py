@@ -33,7 +33,8 @@ class hvla_config(C.Structure):
                                          "action_dim")] + \
                [("tanh_scale", C.c_float), ("max_action", C.c_float)] + \
                [(n, C.c_int32) for n in ("ctx_dim", "ctx_layers", "ctx_heads", "ctx_mlp", "lang_tokens",
-                                         "lang_dim", "scale_context", "max_batch", "enc_dtype", "streams", "clip_target")]
+                                         "lang_dim", "scale_context", "max_batch", "enc_dtype", "streams", "clip_target",
+                                         "layernorm_tail")]
 
 
 class hvla_tensor_desc(C.Structure):
@@ -145,7 +146,8 @@ class NativeError(RuntimeError):
 class Context:
     """One hvla_ctx (one device)."""
 
-    def __init__(self, geometry, device: int = 0, max_batch: int = 256, enc_dtype: str = "f16", streams: int = 1):
+    def __init__(self, geometry, device: int = 0, max_batch: int = 256, enc_dtype: str = "f16", streams: int = 1,
+                 layernorm_tail: bool = False):
         self.lib = load_library()
         g = geometry
         if enc_dtype not in ("f16", "bf16"):
@@ -155,7 +157,7 @@ class Context:
                                g.tanh_scale, g.max_action, g.ctx_dim, g.ctx_layers, g.ctx_heads, g.ctx_mlp,
                                g.lang_tokens, g.lang_dim, int(g.scale_context), int(max_batch),
                                HVLA_ENC_BF16 if enc_dtype == "bf16" else HVLA_ENC_F16, int(streams),
-                               int(getattr(g, "clip_target", True)))
+                               int(getattr(g, "clip_target", True)), int(bool(layernorm_tail)))
         self.geometry, self.device, self.max_batch, self.enc_dtype = g, device, max_batch, enc_dtype
         h = C.c_void_p()
         rc = self.lib.hvla_create(C.byref(self.cfg), device, C.byref(h))

@@ -62,6 +62,10 @@ typedef struct hvla_config {
                                                 >= 64 episodes on two streams, forked from / joined to the caller's  */
   int32_t clip_target;                       /* action_head_kwargs.clip_target (action_heads.py:408,499-500): the loss clips
                                                 the action target to +-max_action iff non-zero                        */
+  int32_t layernorm_tail;                    /* 0 (default): norm1 / norm2 of the image encoder are launches of their own;
+                                                1: they run as tail jobs of the GEMM that writes the residual stream (batches
+                                                of >= 8 images of 256 patches).  The same bytes either way (tests cross them);
+                                                measured slower by 0.3-0.5 ms per step at B = 256, so opt-in.   */
 } hvla_config;
 
 /* One named float32 tensor of the hypernetwork checkpoint, HOST memory, reference naming

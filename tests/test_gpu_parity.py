@@ -891,3 +891,35 @@ def test_tokens_are_the_same_whichever_gemm_kernel_computes_them():
     assert torch.equal(mixed[1], ref[0]) and torch.equal(mixed[3], ref[0]) and torch.equal(mixed[2], last[0])
     pair = m.encode_images(np.ascontiguousarray(im[[39, 0]])).cpu()             # B = 2: the second image's rows straddle 64-row tiles
     assert torch.equal(pair[1], ref[0]) and torch.equal(pair[0], last[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_layernorm_tail_gives_the_bytes_of_the_separate_launch():
+    """hvla_config.layernorm_tail = 1 (opt-in): norm1 / norm2 as tail jobs of the GEMM that writes the residual stream (gemm256p_kernel<..., LNT>: write-through stores, one
+    ticket per column tile, the image's last tile normalises its 257 rows) against the default (the
+    stand-alone layernorm_img_kernel / layernorm_split_kernel launches): the same patch tokens bit for bit, at a batch below one
+    round of workgroups (one tile per workgroup), at a ragged one and at 256 (persistent grid), repeatedly (a stale read or a
+    missed ticket would be a timing matter) and with another stream's copy kernel loading the memory system."""
+    _need_gpu()
+    from hypervla.config import FULL
+    from hypervla.model import HyperVLA
+    from hypervla.synthetic import synthetic_images
+    B = 256
+    im = synthetic_images(B, FULL)[:, 0]
+    sep = HyperVLA.from_synthetic(FULL, max_batch=B)
+    ref = sep.encode_images(im).cpu()
+    del sep
+    m = HyperVLA.from_synthetic(FULL, max_batch=B, layernorm_tail=True)
+    for nb in (8, 9, 40, 255):
+        assert torch.equal(m.encode_images(im[:nb]).cpu(), ref[:nb]), nb
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=m.device)
+    side = torch.cuda.Stream(m.device)
+    for rep in range(12):
+        if rep >= 6:                                        # uneven load: 256 MB copies on another stream while the encoder runs
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    big[: 1 << 27].copy_(big[1 << 27:])
+        tok = m.encode_images(im).cpu()
+        side.synchronize()
+        assert torch.equal(tok, ref), rep
