@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,7 @@ struct hvla_ctx {
   // weight arenas handed back with hvla_weights_free wait here for the next hvla_generate of the same batch size: after
   // the first episode batch hvla_generate does not allocate (include/hvla.h: it can then be captured / does not sync)
   std::vector<hvla_weights*> arena_pool;
+  std::mutex pool_mu;                        // hvla_weights_free can arrive from another thread (Python's GC) than hvla_generate
   static constexpr size_t ARENA_POOL_MAX = 4;
   hipEvent_t ev_bucket[3] = {nullptr, nullptr, nullptr};   // hvla_train_step: gradient buckets final (created on first use)
   bool bucket_recorded[3] = {false, false, false};
@@ -134,6 +136,9 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
                   c->horizon * (c->action_dim - 1) + c->horizon <= 32 && c->max_batch >= 1 &&
                   (c->enc_dtype == HVLA_ENC_F16 || c->enc_dtype == HVLA_ENC_BF16);
   if (!ok) return c->enc_dtype != HVLA_ENC_F16 && c->enc_dtype != HVLA_ENC_BF16 ? HVLA_E_DTYPE : HVLA_E_SHAPE;
+  // the context encoder keeps its token block, q / k / v and the MLP hidden rows in LDS: a geometry that does not fit is
+  // refused here, not at the first hvla_generate
+  if (ctx_encoder_lds_bytes(c->lang_tokens, c->ctx_dim, c->ctx_mlp, c->enc_dim) > 160 * 1024) return HVLA_E_SHAPE;
   if (hipSetDevice(device) != hipSuccess) return HVLA_E_DEVICE;
   ctx->lay = build_layout(g);
   ctx->Kp = 2 * ((g.patch * g.patch * 3 + 63) / 64 * 64);     // [W_hi | W_lo] along K (encoder.hip)
@@ -397,12 +402,15 @@ int hvla_generate(hvla_ctx* ctx, const float* tok, const int64_t* mask, const fl
   const PolicyLayout& pl = ctx->lay.pl;
   const Geom& g = ctx->g;
   std::unique_ptr<hvla_weights> w;
-  for (size_t i = 0; i < ctx->arena_pool.size(); ++i)          // an arena of this batch size handed back earlier
-    if (ctx->arena_pool[i]->B == B) {
-      w.reset(ctx->arena_pool[i]);
-      ctx->arena_pool.erase(ctx->arena_pool.begin() + i);
-      break;
-    }
+  {
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    for (size_t i = 0; i < ctx->arena_pool.size(); ++i)        // an arena of this batch size handed back earlier
+      if (ctx->arena_pool[i]->B == B) {
+        w.reset(ctx->arena_pool[i]);
+        ctx->arena_pool.erase(ctx->arena_pool.begin() + i);
+        break;
+      }
+  }
   if (!w) {
     w.reset(new hvla_weights);
     w->B = B;
@@ -412,8 +420,11 @@ int hvla_generate(hvla_ctx* ctx, const float* tok, const int64_t* mask, const fl
     A(w->ctx, (size_t)B * g.C * 4);
     A(w->ring, (size_t)g.horizon * B * g.horizon * g.action_dim * 4); A(w->count, 16);
     if (e != hipSuccess) {
-      for (hvla_weights* q : ctx->arena_pool) delete q;        // give the pooled arenas back to the device and retry once
-      ctx->arena_pool.clear();
+      {
+        std::lock_guard<std::mutex> lk(ctx->pool_mu);
+        for (hvla_weights* q : ctx->arena_pool) delete q;      // give the pooled arenas back to the device and retry once
+        ctx->arena_pool.clear();
+      }
       e = hipSuccess;
       A(w->wh, (size_t)B * pl.Gm * 2); A(w->wl, (size_t)B * pl.Gm * 2); A(w->vf, (size_t)B * pl.Gv * 4);
       A(w->ctx, (size_t)B * g.C * 4);
@@ -441,8 +452,19 @@ int hvla_weights_free(hvla_ctx* ctx, hvla_weights* w) {
   // hipFree waited for the device; a pooled arena must give the same guarantee before another stream's hvla_generate
   // writes into it (this call has no stream of its own: frees happen at episode resets, not in the step loop)
   (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(ctx->pool_mu);
   if (ctx->arena_pool.size() < hvla_ctx::ARENA_POOL_MAX) ctx->arena_pool.push_back(w);
   else delete w;
+  return HVLA_OK;
+}
+
+int hvla_release_pooled_arenas(hvla_ctx* ctx) {
+  if (!ctx) return HVLA_E_STATE;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(ctx->pool_mu);
+  for (hvla_weights* q : ctx->arena_pool) delete q;
+  ctx->arena_pool.clear();
   return HVLA_OK;
 }
 

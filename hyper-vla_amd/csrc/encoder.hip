@@ -1616,6 +1616,8 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   T* qxs = Vs + SP * AVLD;                                 // [64]       the last query (parked here, not in registers)
   float* part = reinterpret_cast<float*>(qxs + 64);        // [KT][66]   partial (max, sum, O[64]) of the last query
   float* csum = part + KT * 66;                            // [NW][64]   per-wave column sums of the output
+  float* clsrow = csum + NW * 64;                          // [SP]       AMAP only: the CLS query's unnormalised probabilities (a region of
+                                                           // its own: `part` is written by the other waves' tails while wave 0 may still be in pass 2)
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthr = blockDim.x;
   const size_t rowstride = (size_t)3 * E;
@@ -1726,9 +1728,9 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       const f32x2v p2 = {__builtin_amdgcn_exp2f(sc[r] - mx), __builtin_amdgcn_exp2f(sc[r + 1] - mx)};
-      if (AMAP && wave == 0 && col == 0) {                 // query 0 = the CLS token: its unnormalised row waits in `part` (free until the tail)
-        part[kt * 32 + crow(r, half)] = p2[0];
-        part[kt * 32 + crow(r + 1, half)] = p2[1];
+      if (AMAP && wave == 0 && col == 0) {                 // query 0 = the CLS token: its unnormalised row waits in LDS for the denominator
+        clsrow[kt * 32 + crow(r, half)] = p2[0];
+        clsrow[kt * 32 + crow(r + 1, half)] = p2[1];
       }
       lsum2 += p2;
       pf[r >> 3][r & 7] = (T)p2[0];
@@ -1752,7 +1754,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   if (AMAP && wave == 0) {       // outputs.attentions[layer][b, head, 0, 1:] (base_vit.py:117-118, hypervla_interface.py:210-211)
     const float i0 = lane_bcast(inv, 0);
     float* am = amap + (size_t)b * amap_stride + (size_t)head * (S - 1);
-    for (int j = lane; j < S - 1; j += 64) am[j] = part[1 + j] * i0;
+    for (int j = lane; j < S - 1; j += 64) am[j] = clsrow[1 + j] * i0;
   }
   {
     T* op = o + ((size_t)b * S + q) * E + head * 64;
@@ -2148,7 +2150,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
     pf.begin(3, st);
     if (ws.amap)
-      hipLaunchKernelGGL((attention_kernel<Op, true>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
+      hipLaunchKernelGGL((attention_kernel<Op, true>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes + (size_t)KT * 32 * sizeof(float), st,
                          reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr,
                          ws.amap + (size_t)l * H * (S - 1), g.enc_layers * H * (S - 1));
     else

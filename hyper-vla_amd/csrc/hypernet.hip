@@ -533,16 +533,28 @@ hipError_t debug_ctx_stamps(unsigned long long* out) { return hipMemcpyFromSymbo
 #endif
 
 // ---- launchers -----------------------------------------------------------------------------------
-hipError_t launch_ctx_encoder(const CtxParams& p, int B, hipStream_t st) {
-  const int S = p.T + 2;
-  const int ldx = p.C + 4, ldq = 3 * p.C + 4, ldf = p.F + 4;
+// LDS the context encoder needs for a geometry (T task tokens, width C, MLP width F, image width E): hvla_create refuses a
+// configuration that does not fit instead of letting the first hvla_generate fail with a bare HIP error
+static size_t ctx_big_elems(int T, int C, int F, int E) {
+  const int S = T + 2;
+  const int ldq = 3 * C + 4, ldf = F + 4;
   int bigld = ldq > ldf ? ldq : ldf;
   if (bigld < 132) bigld = 132;
   size_t big_elems = (size_t)S * bigld;
-  if (big_elems < (size_t)p.E + CTX_THREADS) big_elems = (size_t)p.E + CTX_THREADS;
+  if (big_elems < (size_t)E + CTX_THREADS) big_elems = (size_t)E + CTX_THREADS;
+  return big_elems;
+}
+size_t ctx_encoder_lds_bytes(int T, int C, int F, int E) {
+  return ((size_t)2 * (T + 2) * (C + 4) + ctx_big_elems(T, C, F, E) + 64) * sizeof(float);
+}
+
+hipError_t launch_ctx_encoder(const CtxParams& p, int B, hipStream_t st) {
+  const int S = p.T + 2;
+  const int ldx = p.C + 4;
+  const size_t big_elems = ctx_big_elems(p.T, p.C, p.F, p.E);
   CtxParams q = p;
   q.big_elems = (int)big_elems;
-  const size_t smem = ((size_t)2 * S * ldx + big_elems + 64) * sizeof(float);      // + the key mask
+  const size_t smem = ((size_t)2 * S * ldx + big_elems + 64) * sizeof(float);      // + the key mask (= ctx_encoder_lds_bytes)
   static bool attr_done[64] = {};                              // per device: the attribute belongs to the device's code object
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);

@@ -34,6 +34,7 @@ struct WeightGenParams {
   int B, Gm, Gv, ntiles;
 };
 hipError_t launch_ctx_encoder(const CtxParams& p, int B, hipStream_t st);
+size_t ctx_encoder_lds_bytes(int T, int C, int F, int E);       // dynamic LDS of ctx_encoder_kernel for a geometry (<= 160 KiB or refused at create)
 hipError_t launch_weightgen(const WeightGenParams& p, int C, hipStream_t st);
 hipError_t launch_export_theta(const __bf16* wh, const __bf16* wl, const float* vf, const int32_t* perm,
                                int Gm, int Gv, int G, int B, float* theta, hipStream_t st);

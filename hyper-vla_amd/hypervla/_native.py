@@ -17,7 +17,7 @@ _ERRORS = {-1: "HVLA_E_SHAPE", -2: "HVLA_E_DTYPE", -3: "HVLA_E_DEVICE", -4: "HVL
            -5: "HVLA_E_HIP", -6: "HVLA_E_WEIGHTS", -7: "HVLA_E_STATE"}
 
 EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights", "hvla_num_generated",
-           "hvla_generate", "hvla_weights_free", "hvla_weights_batch", "hvla_weights_export",
+           "hvla_generate", "hvla_weights_free", "hvla_release_pooled_arenas", "hvla_weights_batch", "hvla_weights_export",
            "hvla_encode", "hvla_policy", "hvla_step", "hvla_ensemble_reset", "hvla_ensemble",
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
@@ -88,6 +88,8 @@ def load_library():
     lib.hvla_generate.restype = C.c_int
     lib.hvla_weights_free.argtypes = [vp, vp]
     lib.hvla_weights_free.restype = C.c_int
+    lib.hvla_release_pooled_arenas.argtypes = [vp]
+    lib.hvla_release_pooled_arenas.restype = C.c_int
     lib.hvla_weights_batch.argtypes = [vp]
     lib.hvla_weights_batch.restype = i32
     lib.hvla_weights_export.argtypes = [vp, vp, vp, vp, vp]
@@ -223,6 +225,10 @@ class Context:
         """Device buffers the following encode / policy / step calls write the two attention maps into (0 = off)."""
         self._check(self.lib.hvla_set_attention_outputs(self.h, C.c_void_p(dino_ptr or None), C.c_void_p(head_ptr or None)),
                     "hvla_set_attention_outputs")
+
+    def release_pooled_arenas(self):
+        """Give the weight arenas parked by `weights_free` back to the device (up to 4 per context stay resident otherwise)."""
+        self._check(self.lib.hvla_release_pooled_arenas(self.h), "hvla_release_pooled_arenas")
 
     def selftest(self, stream: int = 0):
         self._check(self.lib.hvla_selftest(self.h, C.c_void_p(stream)), "hvla_selftest")

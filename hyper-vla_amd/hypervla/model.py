@@ -105,11 +105,18 @@ class HyperVLA:
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def load_pretrained(cls, checkpoint_path: str, step: Optional[int] = None, **kw) -> "HyperVLA":
+    def load_pretrained(cls, checkpoint_path: str, step: Optional[int] = None, audit="raise", **kw) -> "HyperVLA":
         """Reads ``config.json``, ``example_batch.msgpack`` (flax msgpack, read without flax: hypervla/convert.py),
         ``dataset_statistics.json`` and the parameter file written by :meth:`save_pretrained` (``params_<step>.npz`` /
         ``params.npz``; flat '/'-joined flax names) -- the files of hypervla/model.py:152-214 except that
-        the parameters are an npz instead of an Orbax step directory (exporter-only: INTEGRATION.md)."""
+        the parameters are an npz instead of an Orbax step directory (exporter-only: INTEGRATION.md).
+
+        `audit`: what the operand-range audit of the checkpoint's example batch does when activations leave the 16-bit operand
+        type's range -- "raise" (default: refuse the checkpoint), "warn" (load it and warn; `model.operand_range` has the
+        numbers) or False / "off" (no audit: no encoder pass at load time).  When the checkpoint has no example batch the audit
+        cannot run; that is reported with a warning instead of passing silently."""
+        if audit not in ("raise", "warn", "off", False, None):
+            raise ValueError(f"audit must be 'raise', 'warn' or 'off', got {audit!r}")
         with open(os.path.join(checkpoint_path, "config.json")) as f:
             config = json.load(f)
         if "action_head_kwargs" not in config["base_net_kwargs"]:        # model.py:157-163
@@ -129,7 +136,16 @@ class HyperVLA:
             params = {k: z[k] for k in z.files}
         from .convert import load_example_batch
         model = cls(config, params, load_example_batch(checkpoint_path), stats, **kw)
-        model.audit_operand_range()            # a real checkpoint's activations must fit the 16-bit operand type
+        if audit in ("raise", "warn"):         # a real checkpoint's activations must fit the 16-bit operand type
+            import warnings
+            try:
+                if model.audit_operand_range() is None:
+                    warnings.warn("operand-range audit skipped: the checkpoint has no example batch with image_primary frames; "
+                                  "call model.audit_operand_range(images) on real observations", RuntimeWarning)
+            except ValueError as e:
+                if audit == "raise":
+                    raise
+                warnings.warn(f"{e} (audit='warn': loaded anyway)", RuntimeWarning)
         return model
 
     FP16_OPERAND_LIMIT = 32768.0               # half of fp16's largest finite value (65504)
@@ -151,7 +167,7 @@ class HyperVLA:
             img = img[:, 0].contiguous()
         g = self.geometry
         if tuple(img.shape[1:]) != (g.image_size, g.image_size, 3):
-            return None                        # example frames of another size go through preprocess_images first
+            img = self.preprocess_images(img)  # example frames of another size: the evaluators' resize (InferenceWrapper._resize_image)
         img = img[: self.max_batch].contiguous()
         audit = self._ctx.encode_audit(img.data_ptr(), img.shape[0], self._stream())      # {site: (max |x|, non-finite count)}
         sites = {k: v[0] for k, v in audit.items()}

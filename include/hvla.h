@@ -53,7 +53,10 @@ typedef struct hvla_config {
   int32_t dim, layers, heads, mlp;           /* generated vit_t: 64, 4, 4, 128                  */
   int32_t horizon, action_dim;               /* 4, 7                                            */
   float tanh_scale, max_action;              /* 5, 5 (action_heads.py:469-470)                  */
-  int32_t ctx_dim, ctx_layers, ctx_heads, ctx_mlp; /* hypernet: 128, 6, 4, 512                  */
+  int32_t ctx_dim, ctx_layers, ctx_heads, ctx_mlp; /* hypernet: 128, 6, 4, 512.  ctx_mlp % 16 == 0 (the f32 MFMA's column
+                                                tiles), and the context encoder's LDS working set -- (lang_tokens + 2) rows of
+                                                max(3 ctx_dim, ctx_mlp) + 2 ctx_dim floats -- must fit 160 KiB: hvla_create
+                                                returns HVLA_E_SHAPE otherwise                                          */
   int32_t lang_tokens, lang_dim;             /* 32, 768                                         */
   int32_t scale_context;                     /* hypernetwork.py:191-192                         */
   int32_t max_batch;                         /* workspace is sized for this many episodes       */
@@ -98,6 +101,11 @@ int64_t hvla_num_generated(const hvla_ctx* ctx);
 int hvla_generate(hvla_ctx* ctx, const float* token_embedding, const int64_t* attention_mask,
                   const float* initial_cls, int32_t B, hvla_weights** out, void* stream);
 int hvla_weights_free(hvla_ctx* ctx, hvla_weights* w);
+/* hvla_weights_free parks up to 4 arenas per ctx for the next hvla_generate of the same batch size (0.8 MB per episode at the
+ * README geometry: ~0.8 GB stay resident after batches of 256).  This gives them back to the device (waits for the device).
+ * The pool is locked: hvla_weights_free / hvla_release_pooled_arenas may be called from another thread than hvla_generate
+ * (a garbage collector), everything else on a ctx stays single-threaded.                                                   */
+int hvla_release_pooled_arenas(hvla_ctx* ctx);
 int32_t hvla_weights_batch(const hvla_weights* w);
 
 /* Reference-order views for the caller / parity tests (the reference returns these from

@@ -692,6 +692,28 @@ def test_policy_kernel_is_run_to_run_deterministic(full):
         assert int(((lgs != lgs[0]).reshape(runs, -1).any(1)).sum()) == 0
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("flavour", ["product", "bench"])
+def test_policy_kernel_determinism_at_the_batch_that_once_failed(flavour):
+    """profiles/r3_policy_race.txt: the one differing episode of the product build showed at B = 64 (1 in 7 680 episode-runs), and
+    the bench flavour of the library (the same sources with the never-executed time-stamp code compiled in) differed in 3-10 % of
+    them.  20 480 episode-runs at B = 64 of each flavour, in a process of its own (the flavour is chosen when the library is
+    loaded), must all equal the first run bit for bit.  profiles/r4_race_root_cause.txt has what is and is not known."""
+    _need_gpu()
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HVLA_PROBE_EPISODE_RUNS="20480")
+    if flavour == "bench":
+        env["HVLA_LIBRARY_FLAVOUR"] = "bench"
+        if not os.path.exists(os.path.join(root, "hyper-vla_amd", "lib", "libhvla_bench.so")):
+            pytest.fail("libhvla_bench.so is missing: __graft_entry__.build() builds it")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "policy_determinism_probe.py"), "64"], env=env,
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("B=64")][-1]
+    assert "differ from the first run: 0 of 20480" in line, line
+
+
 @pytest.mark.timeout(900)
 def test_config3_size_graph_replay_and_invariance():
     """BASELINE configs[2] size (2048 episodes, hipGraph-captured step with the device-side ensemble): the replayed graph
