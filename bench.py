@@ -26,7 +26,7 @@ for p in (os.path.join(ROOT, "hyper-vla_amd"), ROOT):
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-PMC_ROUND = "r3"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
+PMC_ROUND = "r4"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
 PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
@@ -110,8 +110,26 @@ def finetune_bench(a, model, rank, world, use_dist):
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    # the step's dominant kernel family, timed live on two more steps (HIP events on the launch stream around every batched GEMM
+    # launch: hvla_train_profile): csrc/train.hip bgemm3_kernel, the split-bf16 GEMM of every forward / dX / dW product
+    model._ctx.train_profile(True)
+    for _ in range(2):
+        ft.step(ins, st, images, batch)
+    torch.cuda.synchronize(dev)
+    gemm_ms, gemm_flops, gemm_n = model._ctx.train_profile_read()
+    model._ctx.train_profile(False)
+    f32_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "bgemm3_kernel (csrc/train.hip): every dense product of the step, f32 operands split hi + lo "
+                                           "while staged, THREE v_mfma_f32_32x32x16_bf16 per product (a_hi b_hi + a_hi b_lo + a_lo b_hi)",
+                "achieved": round(3.0 * f32_tflops, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(3.0 * f32_tflops / PEAK_TFLOPS, 4),
+                "f32_equivalent_tflops": round(f32_tflops, 2), "mfma_per_product": 3, "traffic": None,
+                "gemm_ms_per_step": round(gemm_ms / 2, 3), "gemm_launches_per_step": gemm_n // 2,
+                "gemm_flops_per_step_f32_equivalent": gemm_flops / 2,
+                "note": "achieved = matrix-instruction work (3 x the f32-equivalent 2MNK) / summed duration of the GEMM launches; "
+                        "the rest of the step is element-wise kernels and the optimiser"}
     if rank == 0:
         print(json.dumps({
+            "roofline": roofline,
             "metric": "finetune_samples_per_sec", "value": round(whole_job_rate(B, world, a.steps, elapsed), 2),
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -297,7 +315,8 @@ def main():
 
     # ---- per-step latency distribution + full kernel breakdown (separate, un-timed passes)
     lat = []
-    n_lat = max(a.steps, 200) if a.graph else min(a.steps, 20)      # config 3: p50 over >= 200 replays
+    # p50 over >= 200 samples for a replayed graph (config 3) and for the small batches whose metric IS the latency (B <= 8)
+    n_lat = max(a.steps, 200) if (a.graph or B <= 8) else min(a.steps, 20)
     for _ in range(n_lat):
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()

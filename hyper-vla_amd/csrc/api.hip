@@ -702,6 +702,21 @@ int hvla_train_wait_bucket(hvla_ctx* ctx, int32_t bucket, void* stream) {
   return HVLA_OK;
 }
 
+int hvla_train_profile(hvla_ctx* ctx, int32_t on) {
+  if (!ctx) return HVLA_E_STATE;
+  train_gemm_timer(on != 0);
+  return HVLA_OK;
+}
+
+int hvla_train_profile_read(hvla_ctx* ctx, float* gemm_ms, double* gemm_flops, int32_t* launches) {
+  if (!ctx || !gemm_ms || !gemm_flops || !launches) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int n = 0;
+  HIPCHK(ctx, train_gemm_timer_read(gemm_ms, gemm_flops, &n));
+  *launches = n;
+  return HVLA_OK;
+}
+
 int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_train_hyper* hy, void* stream) {
   if (!ctx || !buf || !hy) return HVLA_E_STATE;
   if (!buf->params || !buf->grads || !buf->mu || !buf->nu || !buf->sqsum) FAIL(ctx, HVLA_E_SHAPE, "null pointer");

@@ -472,17 +472,22 @@ __global__ __launch_bounds__(256, 3) void weightgen_kernel(WeightGenParams p) { 
         h1[j] = hi, l1[j] = lo;
       }
       __syncthreads();                           // the previous episode tile's rows have been read
-      bf16x8* sh = reinterpret_cast<bf16x8*>(&stage[0][col][wave * 32 + half * 16]);
-      bf16x8* sl = reinterpret_cast<bf16x8*>(&stage[1][col][wave * 32 + half * 16]);
-      sh[0] = h0, sh[1] = h1, sl[0] = l0, sl[1] = l1;
+      // A row is 256 B = twice the 32 write banks, and the eight lanes of a ds_write_b128 group hold eight consecutive rows at ONE
+      // position: eight-way conflicts on every write (65 % of this kernel's LDS cycles, profiles/r3_pmc_sq_by_kernel.csv).  The
+      // 16-byte chunk index is XORed with the row, here and where the rows are read back: both sides are conflict-free.
+      const int c0 = wave * 4 + half * 2, sx = col & 15;
+      *reinterpret_cast<bf16x8*>(&stage[0][col][((c0 + 0) ^ sx) * 8]) = h0;
+      *reinterpret_cast<bf16x8*>(&stage[0][col][((c0 + 1) ^ sx) * 8]) = h1;
+      *reinterpret_cast<bf16x8*>(&stage[1][col][((c0 + 0) ^ sx) * 8]) = l0;
+      *reinterpret_cast<bf16x8*>(&stage[1][col][((c0 + 1) ^ sx) * 8]) = l1;
       __syncthreads();
       const size_t gpos = (size_t)wg * 128 + (lane & 15) * 8;          // 16 lanes x 16 B = one episode's 256-byte run
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int row = wave * 8 + u * 4 + (lane >> 4);
         if (b0 + row < p.B) {
-          const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&stage[0][row][(lane & 15) * 8]);
-          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&stage[1][row][(lane & 15) * 8]);
+          const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&stage[0][row][((lane & 15) ^ (row & 15)) * 8]);
+          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&stage[1][row][((lane & 15) ^ (row & 15)) * 8]);
           *reinterpret_cast<bf16x8*>(p.wh + (size_t)(b0 + row) * p.Gm + gpos) = vh;
           *reinterpret_cast<bf16x8*>(p.wl + (size_t)(b0 + row) * p.Gm + gpos) = vl;
         }

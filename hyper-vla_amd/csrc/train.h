@@ -27,6 +27,8 @@ struct BG {
   long sBias1 = 0;            // bias stride of the inner batch index b1
 };
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0);
+void train_gemm_timer(bool on);                                                  // hvla_train_profile
+hipError_t train_gemm_timer_read(float* ms, double* flops, int* launches);      // since the last read
 
 // flat layout of the trainable hypernetwork parameters (float32 elements)
 // `total` = the hypernetwork's own parameters; the shared DINOv2 leaves follow at [total, total + enc_total) when the

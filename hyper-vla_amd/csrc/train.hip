@@ -356,7 +356,47 @@ static bool train_gemm_exact() { return g_train_gemm_exact; }
 static constexpr bool train_gemm_exact() { return false; }
 #endif
 
+// Optional live timing of the batched GEMM launches (hvla_train_profile: bench.py --finetune's `roofline` block): HIP events on
+// the launch stream around every bgemm() call and the f32-equivalent work of the call (2 M N K per batch entry; the split-bf16
+// kernel spends three matrix instructions per product).  Off by default; not thread-safe (one training stream per process).
+namespace {
+struct GemmTimer {
+  bool on = false;
+  std::vector<hipEvent_t> a, b;
+  size_t used = 0;
+  double flops = 0.0;
+} g_gemm_timer;
+}  // namespace
+void train_gemm_timer(bool on) { g_gemm_timer.on = on; }
+hipError_t train_gemm_timer_read(float* ms, double* flops, int* launches) {
+  GemmTimer& t = g_gemm_timer;
+  *ms = 0.f; *flops = t.flops; *launches = (int)t.used;
+  for (size_t i = 0; i < t.used; ++i) {
+    hipError_t e = hipEventSynchronize(t.b[i]);
+    if (e != hipSuccess) return e;
+    float x = 0.f;
+    if ((e = hipEventElapsedTime(&x, t.a[i], t.b[i])) != hipSuccess) return e;
+    *ms += x;
+  }
+  t.used = 0; t.flops = 0.0;
+  return hipSuccess;
+}
+static void bgemm_launch(hipStream_t st, bool ta, bool tb, BG g, int nb0);
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
+  GemmTimer& t = g_gemm_timer;
+  if (!t.on) { bgemm_launch(st, ta, tb, g, nb0); return; }
+  if (t.used == t.a.size()) {
+    hipEvent_t x, y;
+    if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) { bgemm_launch(st, ta, tb, g, nb0); return; }
+    t.a.push_back(x), t.b.push_back(y);
+  }
+  (void)hipEventRecord(t.a[t.used], st);
+  bgemm_launch(st, ta, tb, g, nb0);
+  (void)hipEventRecord(t.b[t.used], st);
+  ++t.used;
+  t.flops += 2.0 * g.M * g.N * g.K * (double)nb0 * g.nb1;
+}
+static void bgemm_launch(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
   const bool exact = train_gemm_exact();
   const int T = !exact && g.M >= 96 && g.N >= 96 ? 128 : 64;
   // deep-K products onto few output tiles (shared-weight gradients: K = all rows of the batch) would leave most CUs

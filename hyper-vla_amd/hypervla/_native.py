@@ -22,7 +22,7 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
            "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit", "hvla_train_accumulate", "hvla_train_bucket_ranges",
-           "hvla_train_wait_bucket", "hvla_set_attention_outputs"]
+           "hvla_train_wait_bucket", "hvla_set_attention_outputs", "hvla_train_profile", "hvla_train_profile_read"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy",
               "small_row_gemms"]      # mean rows + the 2 B latency-bound rows per GEMM: CLS rows and weight-rounding compensation rows
 
@@ -126,6 +126,10 @@ def load_library():
     lib.hvla_train_bucket_ranges.restype = C.c_int
     lib.hvla_train_wait_bucket.argtypes = [vp, i32, vp]
     lib.hvla_train_wait_bucket.restype = C.c_int
+    lib.hvla_train_profile.argtypes = [vp, i32]
+    lib.hvla_train_profile.restype = C.c_int
+    lib.hvla_train_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i32)]
+    lib.hvla_train_profile_read.restype = C.c_int
     lib.hvla_train_apply.restype = C.c_int
     lib.hvla_profile.argtypes = [vp, i32]
     lib.hvla_profile.restype = C.c_int
@@ -225,6 +229,15 @@ class Context:
         """Device buffers the following encode / policy / step calls write the two attention maps into (0 = off)."""
         self._check(self.lib.hvla_set_attention_outputs(self.h, C.c_void_p(dino_ptr or None), C.c_void_p(head_ptr or None)),
                     "hvla_set_attention_outputs")
+
+    def train_profile(self, on: bool):
+        self._check(self.lib.hvla_train_profile(self.h, int(bool(on))), "hvla_train_profile")
+
+    def train_profile_read(self):
+        """(ms summed over the fine-tune step's batched GEMM launches, their f32-equivalent FLOPs, launches) since the last read."""
+        ms, fl, n = C.c_float(), C.c_double(), C.c_int32()
+        self._check(self.lib.hvla_train_profile_read(self.h, C.byref(ms), C.byref(fl), C.byref(n)), "hvla_train_profile_read")
+        return ms.value, fl.value, n.value
 
     def release_pooled_arenas(self):
         """Give the weight arenas parked by `weights_free` back to the device (up to 4 per context stay resident otherwise)."""

@@ -221,6 +221,12 @@ int hvla_train_apply(hvla_ctx* ctx, const hvla_train_buffers* buf, const hvla_tr
  * hvla_train_step is final, without blocking the host: the caller then enqueues its all-reduce of that range there.     */
 int hvla_train_bucket_ranges(hvla_ctx* ctx, int32_t train_encoder, int64_t out[6]);
 int hvla_train_wait_bucket(hvla_ctx* ctx, int32_t bucket, void* stream);
+/* Measurement only (bench.py --finetune `roofline`): while on, every batched GEMM launch of hvla_train_step (the split-bf16
+ * kernel that carries ~80 % of the step: forward, input-gradient and weight-gradient products) is bracketed by HIP events on the
+ * launch stream.  hvla_train_profile_read returns, since the last read, the summed milliseconds of those launches, their
+ * f32-equivalent work (2 M N K each; three bf16 matrix instructions per product on the hardware) and their number.           */
+int hvla_train_profile(hvla_ctx* ctx, int32_t on);
+int hvla_train_profile_read(hvla_ctx* ctx, float* gemm_ms, double* gemm_flops, int32_t* launches);
 /* Replaces: one micro-step of optax.MultiSteps under the reference's chain(clip_by_global_norm, MultiSteps(adamw))
  * (octo/utils/train_utils.py:420-426, grad_accumulation_steps > 1): acc += clip_by_global_norm(buf->grads) * inv_k.
  * After k micro-steps the caller runs hvla_train_apply with `grads` pointing at acc and hyper.clip = +inf.        */
