@@ -88,14 +88,17 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   const float u = k0 * (x + k1 * x * x * x);
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u));
 }
-// exact-erf GELU (HF ACT2FN["gelu"]).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 round-off level)
-// instead of libm erff, which matters because the fc1 epilogue applies it to B*257*3072 values per layer with the matrix
-// pipe idle.  Written for pairs so that everything except v_rcp / v_exp is a packed f32 instruction, and in the even form
-//   gelu(x) = max(x, 0) - (|x| / 2) P(t) exp(-x^2 / 2),   t = 1 / (1 + p |x| / sqrt 2),
-// (x erf(x / sqrt 2) is even in x) which needs no sign transfer and has no cancellation for negative x: 15 issue slots
-// per element, 8 of them the two quarter-rate transcendentals.
+// exact-erf GELU (HF ACT2FN["gelu"]): the fc1 epilogue applies it to B*257*3072 values per layer with the matrix pipe idle, so its
+// instruction count is step time (measured: an fc1 tile is 3.4 us longer than a QKV tile of the same K).  Even form, no sign
+// transfer and no cancellation for negative x:
+//   gelu(x) = max(x, 0) - |x| Phi(-|x|),   Phi(-a) = erfc(a / sqrt 2) / 2 = exp2(q(a)),
+// q = a degree-6 minimax fit of log2 Phi(-a) on [0, 8] weighted by a Phi(-a) (tools/fit_gelu.py; |error of the product| <= 5.2e-8
+// in exact arithmetic, 8.7e-8 evaluated in f32 -- Abramowitz-Stegun 7.1.26, which this replaces, has 2.1e-7 and needs a
+// reciprocal as well: two quarter-rate transcendentals per element instead of one).  Beyond 8 the exponent is held (the
+// polynomial is not monotone out there): the product is then below 2^-50 |x|.  Six packed fmas, one v_exp_f32, min / max per element.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+#ifdef HVLA_EXP_GELU_AS
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {      // round 1-3's form, kept for same-box A/B runs (tools/build_variants.sh)
   const f32x2 ax = __builtin_elementwise_abs(x);
   const f32x2 d = __builtin_elementwise_fma(ax, f32x2{0.2316418882f, 0.2316418882f}, f32x2{1.f, 1.f});   // 0.3275911 / sqrt 2
   const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
@@ -111,6 +114,21 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   const f32x2 m = __builtin_elementwise_max(x, f32x2{0.f, 0.f});
   return __builtin_elementwise_fma(-h, e, m);
 }
+#else
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 a = __builtin_elementwise_min(ax, f32x2{8.f, 8.f});
+  f32x2 q = __builtin_elementwise_fma(a, f32x2{3.309331805212423e-05f, 3.309331805212423e-05f}, f32x2{-0.0007692242506891489f, -0.0007692242506891489f});
+  q = __builtin_elementwise_fma(q, a, f32x2{0.008080732077360153f, 0.008080732077360153f});
+  q = __builtin_elementwise_fma(q, a, f32x2{-0.05341212823987007f, -0.05341212823987007f});
+  q = __builtin_elementwise_fma(q, a, f32x2{-0.4587709605693817f, -0.4587709605693817f});
+  q = __builtin_elementwise_fma(q, a, f32x2{-1.1512017250061035f, -1.1512017250061035f});
+  q = __builtin_elementwise_fma(q, a, f32x2{-0.999993085861206f, -0.999993085861206f});
+  const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+  const f32x2 m = __builtin_elementwise_max(x, f32x2{0.f, 0.f});
+  return __builtin_elementwise_fma(-ax, e, m);
+}
+#endif
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
 
 }  // namespace hvla

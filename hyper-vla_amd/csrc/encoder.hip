@@ -120,6 +120,10 @@ struct GemmArgs {
   void* ln_abar = nullptr;       // 16-bit [B][2][N]
   uint32_t* ln_cnt = nullptr;    // [B] tickets, zero between launches (the last arriver puts the zero back)
   uint32_t out_bytes = 0;        // size of `out` in bytes (buffer descriptor of the write-through stores)
+  // gemm64c_kernel<..., FOLD = true> (the GEMM behind a LayerNorm at a small batch): the mean rows are not read from abar2 but
+  // added up by every workgroup from layernorm_split_kernel's partial column sums [image][half][LNW][K] f32, with
+  // layernorm_mean_kernel's arithmetic -- that launch (two per layer, 4.5 us + a kernel boundary each at B = 1) is gone
+  const float* ln_partial = nullptr;
 };
 
 // Row-major epilogue shared by the three GEMM kernels.  They run the MFMA with the activation fragment as the first
@@ -466,8 +470,14 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
 // that the epilogue reads instead of a table in memory: the separate table launch in front of every GEMM (48 per step,
 // 12 us each at B = 1) is gone.  Same operands, same MFMA, same k order as gemm64_body<EPI_CORR> => the same bias rows.
 constexpr int SNSC = 5, SSTC = 28672;   // stages x (A 8 KB | W 8 KB | dW 8 KB | mean rows 4 KB)
-template <typename Op, int EPI>
+constexpr int LNW = 16;                 // waves of layernorm_img_kernel = workgroups per image of layernorm_split_kernel = partials per mean row
+// FOLD: the mean rows of ALL K-tiles sit in a table behind the stages ([K-tile][16 rows][128 B], a stage's mean-row image), written
+// once in the prologue from the LayerNorm's partial sums (GemmArgs::ln_partial); a stage is then A | W | dW = 24 KB, six pieces.
+constexpr int SSTF = 24576;
+constexpr size_t gemm64c_fold_lds(int K) { return (size_t)SNSC * SSTF + (size_t)(K / 64) * 2048; }
+template <typename Op, int EPI, bool FOLD = false>
 __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
+  constexpr int SST = FOLD ? SSTF : SSTC, PCS = FOLD ? 6 : 7;        // stage stride, LDS-DMA pieces per wave and K-tile
   using T = typename Op::elem;
   using X8 = typename Op::x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -508,14 +518,14 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
                  : "=&s"(keep) : "v"(vo), "s"(sb), "s"(dst));
   };
   auto issue_at = [&](int kt, int slot) {           // K-tile kt into the stage of tile `slot`
-    const uint32_t base = lds0 + (uint32_t)((slot % SNSC) * SSTC + wave * 1024);
+    const uint32_t base = lds0 + (uint32_t)((slot % SNSC) * SST + wave * 1024);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       dma(A, aoff[j] + kt * 64, base + j * 4096);
       dma(W, woff[j] + kt * 64, base + 8192 + j * 4096);
       dma(dW, woff[j] + kt * 64, base + 16384 + j * 4096);
     }
-    dma(AB, boff + kt * 64, base + 24576);
+    if constexpr (!FOLD) dma(AB, boff + kt * 64, base + 24576);
   };
   f32x4 acc[4][1], acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -526,6 +536,33 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
   const int d_off = 16384 + (wave * 16 + fr) * 128, b_off = 24576 + fr * 128;
 #pragma unroll
   for (int s = 0; s < SNSC - 1; ++s) issue_at(s < KT ? s : KT - 1, s);
+  char* mtab = smem + SNSC * SST;                     // FOLD: [KT][16 rows][128 B]
+  if constexpr (FOLD) {
+    // mean row r of the table = (image, half) img0 * 2 + r, for the images this block's rows belong to (the MFMA's other rows are
+    // never written: their products land in accumulator rows nobody reads).  layernorm_mean_kernel's arithmetic: the LNW partials
+    // in wave order, x 1 / rows of the half, rounded to the operand type.  Element (r, k) goes where the LDS-DMA of a [row][K]
+    // matrix would have put it: K-tile k / 64, 16-byte chunk ((k % 64) / 8) ^ (r & 7) of the row's 128 bytes.
+    int mlast = m0 + SBM - 1;
+    mlast = mlast < g.M ? mlast : g.M - 1;
+    const int nr = 2 * ((g.row0 + mlast * g.row_step) / g.S - img0 + 1);       // <= 16 (the host checks S >= 9)
+    const int n4 = g.K / 4;
+    for (int it = tid; it < nr * n4; it += 256) {
+      const int r = it / n4, c4 = it - r * n4, bh = img0 * 2 + r;
+      const f32x4* pp = reinterpret_cast<const f32x4*>(g.ln_partial + (size_t)bh * LNW * g.K) + c4;
+      f32x4 pv[LNW];
+#pragma unroll
+      for (int w = 0; w < LNW; ++w) pv[w] = pp[w * n4];
+      f32x4 t = pv[0];
+#pragma unroll
+      for (int w = 1; w < LNW; ++w) t += pv[w];
+      const float inv = 1.f / (float)((bh & 1) ? g.S - g.hsplit : g.hsplit);
+      typename Op::x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (T)(t[j] * inv);
+      const int k = 4 * c4;
+      *reinterpret_cast<typename Op::x4*>(mtab + (k >> 6) * 2048 + r * 128 + ((((k & 63) >> 3) ^ (r & 7)) << 4) + (k & 7) * 2) = o;
+    }
+  }
   // One workgroup per CU (140 KB of stages) and at B = 1 only 60-240 workgroups in all: nothing but this workgroup's own waves
   // can hide its LDS round trip, so the fragments of K-tile kt + 1 are read while the MFMAs of tile kt run (two register
   // sets).  The MFMA chain of every accumulator is the one it always was: same bits.
@@ -533,7 +570,7 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     X8 fa[2], fw[4][2], fb[2], fd[2];
   };
   auto read_frags = [&](int t, Frags& f) {
-    const char* lb = smem + (t % SNSC) * SSTC;
+    const char* lb = smem + (t % SNSC) * SST;
     f.fa[0] = *reinterpret_cast<const X8*>(lb + a_off + sw0);
     f.fa[1] = *reinterpret_cast<const X8*>(lb + a_off + sw1);
 #pragma unroll
@@ -541,17 +578,18 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
       f.fw[nt][0] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw0);
       f.fw[nt][1] = *reinterpret_cast<const X8*>(lb + w_off + nt * 2048 + sw1);
     }
-    f.fb[0] = *reinterpret_cast<const X8*>(lb + b_off + sw0);
-    f.fb[1] = *reinterpret_cast<const X8*>(lb + b_off + sw1);
+    const char* mb = FOLD ? mtab + (t < KT ? t : KT - 1) * 2048 + fr * 128 : lb + b_off;   // (past the end: the last K-tile again, unused)
+    f.fb[0] = *reinterpret_cast<const X8*>(mb + sw0);
+    f.fb[1] = *reinterpret_cast<const X8*>(mb + sw1);
     f.fd[0] = *reinterpret_cast<const X8*>(lb + d_off + sw0);
     f.fd[1] = *reinterpret_cast<const X8*>(lb + d_off + sw1);
   };
   // No branch inside a step (behind a join the compiler's wait for `cur` becomes lgkmcnt(0), i.e. also waits for `nxt`): past
   // the end the reads fetch a stale stage and the DMA stages the last K-tile once more, both unused -- and every step has the
   // same SNSC - 3 younger tiles in flight when it waits for tile kt + 1, so that wait is the constant vmcnt(14).
-  static_assert(SNSC == 5, "the wait constants below are for five stages of seven pieces");
+  static_assert(SNSC == 5, "the wait constants below are for five stages of PCS pieces");
   auto step = [&](int kt, const Frags& cur, Frags& nxt) {
-    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PCS) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();                    // tile kt + 1 is in LDS for every wave, and every wave holds tile kt - 1's fragments (its MFMAs needed them)
     asm volatile("" ::: "memory");                   // (see gemm64_body)
@@ -568,7 +606,8 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     }
   };
   Frags f0, f1;
-  asm volatile("s_waitcnt vmcnt(21)" ::: "memory");  // tile 0 (the prologue issued four tiles, past the end the last one again)
+  // tile 0 (the prologue issued four tiles, past the end the last one again); FOLD: this wave's table entries are in LDS
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PCS) : "memory");
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -784,7 +823,6 @@ __device__ __forceinline__ float wave64_sum(float v) {
   return (lane_bcast(t, 0) + lane_bcast(t, 16)) + (lane_bcast(t, 32) + lane_bcast(t, 48));
 }
 
-constexpr int LNW = 16;
 // one row: statistics (f32, two passes over the registers), the f32 outputs y (what the column sums add) and the 16-bit store.
 // Shared by the one-workgroup-per-image kernel and the split form below, so that a row and its contribution to the mean row
 // are the same bits in both.
@@ -1973,6 +2011,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm64_kernel<Op, EPI_RES>)) SETA((gemm64_kernel<Op, EPI_CORR>))
     SETA((gemm64_kernel<Op, EPI_QKV, 4>)) SETA((gemm64_kernel<Op, EPI_GELU, 4>)) SETA((gemm64_kernel<Op, EPI_RES, 4>))
     SETA((gemm64c_kernel<Op, EPI_QKV>)) SETA((gemm64c_kernel<Op, EPI_GELU>)) SETA((gemm64c_kernel<Op, EPI_RES>)) SETA((gemm64c32_kernel<Op>))
+    SETA((gemm64c_kernel<Op, EPI_QKV, true>)) SETA((gemm64c_kernel<Op, EPI_GELU, true>))
 #undef SETA
     di.attr[opi] = true;
   }
@@ -1994,6 +2033,12 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   // ln_s / ln_b (RES only): scale and bias of the LayerNorm that follows this GEMM; the image-aligned form runs it as its tail
   // (GemmArgs::ln_*) and sets ln_fused, otherwise the caller launches it.
   bool ln_fused = false;
+  // small batch: does the GEMM [M][K] x [N][K] run as gemm64c_kernel (bias rows computed inside)?  ...and may it also add up the
+  // mean rows from the LayerNorm's partials (FOLD)?  ln_partial: set by layernorm() when it left the mean rows to its consumer.
+  auto small_fused = [&](int N, int K) {
+    return comp && M <= G64_MAXM && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31) && N % SBN == 0 && K % 64 == 0 && S >= 9;
+  };
+  const float* ln_partial = nullptr;
   const bool can_fuse_ln = ws.ln_cnt != nullptr && (size_t)M * E * 4 < (1ull << 32) && E <= 1024;
   auto gemm = [&](auto epic, const void* A, const void* Wt, const void* dW, int N, int K, const float* bias, const float* aux,
                   void* out, int qcols, int cat, void* colmean = nullptr, const float* ln_s = nullptr, const float* ln_b = nullptr) -> bool {
@@ -2044,11 +2089,21 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       return true;
     }
     if constexpr (EPI != EPI_PATCH) {
-      if (comp && M <= G64_MAXM && fits32 && N % SBN == 0 && K % 64 == 0 && S >= 5) {     // small batch: the bias rows are computed inside the GEMM
+      // (S >= 9: a block's 64 rows then belong to at most 8 images = the 16 rows of the kernels' bias-row tile)
+      if (small_fused(N, K)) {                           // small batch: the bias rows are computed inside the GEMM
         a.abar2 = ws.abar; a.dW2 = dW; a.M2 = 2 * B;
         pf.end(CAT_COMP, st);
         pf.begin(cat, st);
         const int nb64 = ((M + SBM - 1) / SBM) * (N / SBN);
+        if constexpr (EPI != EPI_RES) {
+          if (ln_partial) {                              // the LayerNorm in front left the mean rows to this launch
+            a.ln_partial = ln_partial;
+            ln_partial = nullptr;
+            hipLaunchKernelGGL((gemm64c_kernel<Op, EPI, true>), dim3(nb64), dim3(256), gemm64c_fold_lds(K), st, a);
+            pf.end(cat, st);
+            return false;
+          }
+        }
         if constexpr (EPI == EPI_RES) {
           if (2 * nb64 <= ncu) {                     // less than half of the chip: 64 x 32 tiles on twice as many CUs
             hipLaunchKernelGGL((gemm64c32_kernel<Op>), dim3(2 * nb64), dim3(256), SNS32 * SST32, st, a);
@@ -2076,13 +2131,25 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     return false;
   };
   constexpr int LN_SPLIT_MAXB = 64;    // up to here a LayerNorm is LNW workgroups per image + a finalising launch (same bits)
-  auto layernorm = [&](const float* sc, const float* bi) {           // norm1 / norm2 (+ the column sums of the output)
-    if (B <= LN_SPLIT_MAXB && E <= 1024 && (size_t)2 * LNW * E * sizeof(float) <= (size_t)S * F * sizeof(T)) {
-      float* partial = comp ? reinterpret_cast<float*>(ws.g) : nullptr;      // ws.g is free at both LayerNorms: [B][2][LNW][E] f32
+  // Nnext: width of the GEMM that reads the output.  scratch / scratch_cols: a 16-bit [M][scratch_cols] workspace buffer that is free
+  // from this launch until its consumer GEMM has ENDED (norm1: ws.g, QKV writes ws.qkv; norm2: ws.qkv, fc1 writes ws.g), for the
+  // partial column sums [B][2][LNW][E] f32
+  auto layernorm = [&](const float* sc, const float* bi, int Nnext, void* scratch, int scratch_cols) {   // norm1 / norm2 (+ the column sums of the output)
+    if (B <= LN_SPLIT_MAXB && E <= 1024 && (size_t)2 * LNW * E * sizeof(float) <= (size_t)S * scratch_cols * sizeof(T)) {
+      float* partial = comp ? reinterpret_cast<float*>(scratch) : nullptr;
       hipLaunchKernelGGL((layernorm_split_kernel<Op>), dim3(LNW, B), dim3(LNW * 64), (size_t)((S + LNW - 1) / LNW) * E * sizeof(float),
                          st, ws.x, reinterpret_cast<T*>(ws.h), sc, bi, partial, S, E, hsplit);
       // (one launch with the image's last workgroup to arrive -- ticket by atomicAdd behind a __threadfence -- adding the
       // partials was tried: 14.0 us against 5.2 + 4.7 for the two launches, profiles/r3_experiments_not_kept.txt)
+#ifndef HVLA_EXP_NOFOLD
+      // B = 1: every workgroup of the consumer GEMM adds the partials up itself (gemm64c_kernel, FOLD) -- while that GEMM is ONE round
+      // of workgroups.  Same box, ms per step: B = 1 1.250 against 1.270 with the separate launch; B = 4 (612 workgroups, each re-adding
+      // 196 KB through its CU's memory pipe in front of its K loop) 1.93 against 1.85, so from two rounds on the launch stays.
+      if (comp && small_fused(Nnext, E) && gemm64c_fold_lds(E) <= 160 * 1024 && ((M + SBM - 1) / SBM) * (Nnext / SBN) <= ncu) {
+        ln_partial = partial;
+        return;
+      }
+#endif
       if (comp) hipLaunchKernelGGL((layernorm_mean_kernel<Op>), dim3(2 * B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), S, E, hsplit);
       return;
     }
@@ -2142,7 +2209,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     const EncLayerW& L = w.layer[l];
     if (!ln_fused) {                    // norm1: otherwise done as the tail of the previous layer's fc2 / of the patch embedding
       pf.begin(1, st);
-      layernorm(L.ln1_s, L.ln1_b);
+      layernorm(L.ln1_s, L.ln1_b, 3 * E, ws.g, F);
       pf.end(1, st);
     }
     audit_of(ws.h, (size_t)M * E, 0);
@@ -2162,7 +2229,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     gemm(ER{}, ws.h, L.wo, L.dwo, E, E, L.bo, L.ls1, ws.x, 0, 4, nullptr, L.ln2_s, L.ln2_b);   // the attention kernel wrote the mean row itself; norm2 as the tail
     if (!ln_fused) {
       pf.begin(1, st);
-      layernorm(L.ln2_s, L.ln2_b);
+      layernorm(L.ln2_s, L.ln2_b, F, ws.qkv, 3 * E);
       pf.end(1, st);
     }
     audit_of(ws.h, (size_t)M * E, 0);
