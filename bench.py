@@ -40,6 +40,20 @@ def fc1_main_rows(B, g):
     return M
 
 
+def launches_per_step(g, B):
+    """Kernel launches of one eager hvla_step (csrc/encoder.hip run_encoder + the policy): per encoder layer two LayerNorms, four
+    GEMMs and the attention, plus what the batch size adds -- B >= 8: a small-row launch in front of every GEMM (11 per layer; 13 up
+    to 64 images, where a LayerNorm is two launches); B <= 7: the GELU column means (8 per layer at B = 1, where the consumer GEMM
+    adds the LayerNorm partials up itself; 10 otherwise); plus im2col, CLS rows, patch GEMM, final LayerNorm and the policy."""
+    S = g.patches + 1
+    if B * S <= 2047:
+        one_round = ((B * S + 63) // 64) * (max(3 * g.enc_dim, g.enc_mlp) // 64) <= 256
+        per = 8 if one_round else 10
+    else:
+        per = 11 if B > 64 else 13
+    return per * g.enc_layers + 5
+
+
 def algorithmic_flops(g):
     """Per sample-step, counted as the reference executes them (SURVEY.md §8d / BASELINE.md §2)."""
     S, E, F, P, D, M, L = g.seq, g.enc_dim, g.enc_mlp, g.patches, g.dim, g.mlp, g.layers
@@ -376,7 +390,7 @@ def main():
                    "encoder_operands": a.enc_dtype + " (+ per-image first-order compensation of the weight rounding, "
                                        "kernel_ms_per_step.small_row_gemms)",
                    "policy_operands": "split-bf16 (bf16x3)",
-                   "launch": "hipGraph replay" if a.graph else f"eager (about {13 * g.enc_layers + 6} launches per step)",
+                   "launch": "hipGraph replay" if a.graph else f"eager ({launches_per_step(g, B)} launches per step)",
                    "streams": a.streams,
                    "ensemble": "device-side un-normalise + temporal ensemble (history = horizon) inside the step"
                                if ens is not None else "not in the step"},

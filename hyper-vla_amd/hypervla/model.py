@@ -103,6 +103,11 @@ class HyperVLA:
             raise ValueError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:3]}")
         self._ctx.load_weights({k: params[k] for k in want})
 
+    def release_pooled_arenas(self) -> None:
+        """Free the generated-weight arenas that freed `GeneratedWeights` parked for re-use (hvla_release_pooled_arenas:
+        up to four per context, about 0.8 MB per episode each).  `create_tasks` allocates again when it next needs one."""
+        self._ctx.release_pooled_arenas()
+
     # ------------------------------------------------------------------ construction
     @classmethod
     def load_pretrained(cls, checkpoint_path: str, step: Optional[int] = None, audit="raise", **kw) -> "HyperVLA":
