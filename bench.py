@@ -44,14 +44,14 @@ def launches_per_step(g, B):
     """Kernel launches of one eager hvla_step (csrc/encoder.hip run_encoder + the policy): per encoder layer two LayerNorms, four
     GEMMs and the attention, plus what the batch size adds -- B >= 8: a small-row launch in front of every GEMM (11 per layer; 13 up
     to 64 images, where a LayerNorm is two launches); B <= 7: the GELU column means (8 per layer at B = 1, where the consumer GEMM
-    adds the LayerNorm partials up itself; 10 otherwise); plus im2col, CLS rows, patch GEMM, final LayerNorm and the policy."""
+    adds the LayerNorm partials up itself; 10 otherwise); plus im2col (+ CLS rows), patch GEMM, final LayerNorm and the policy."""
     S = g.patches + 1
     if B * S <= 2047:
         one_round = ((B * S + 63) // 64) * (max(3 * g.enc_dim, g.enc_mlp) // 64) <= 256
         per = 8 if one_round else 10
     else:
         per = 11 if B > 64 else 13
-    return per * g.enc_layers + 5
+    return per * g.enc_layers + 4
 
 
 def algorithmic_flops(g):

@@ -42,9 +42,13 @@ namespace hvla {
 // fp16/bf16, and the weight matrix is [W_hi | W_lo] so the single 16-bit GEMM over K = 2*Kp1 computes
 // a . (W_hi + W_lo): the patch embedding is then accurate to ~2^-20 instead of 2^-11 (it dominated
 // the encoder's error when W was rounded once).
+// The same launch also writes the B CLS rows of the residual stream (x[b * S] = pos[0], which carries cls_token + position 0: one
+// launch less per step -- at B = 1 a launch is ~5 us of a 1.2 ms step).
 template <typename Op>
 __global__ void im2col_kernel(const uint8_t* __restrict__ img, typename Op::elem* __restrict__ out, int B,
-                              int image, int patch, int grid, int Kp) {
+                              int image, int patch, int grid, int Kp, float* __restrict__ x, const float* __restrict__ pos, int S, int E) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * E; i += (size_t)gridDim.x * blockDim.x)
+    x[(i / E) * S * E + (i % E)] = pos[i % E];
   // one thread = 8 consecutive k of one patch row
   const int chunks = Kp / 8, Kp1 = Kp / 2;
   const size_t total = (size_t)B * grid * grid * chunks;
@@ -71,11 +75,6 @@ __global__ void im2col_kernel(const uint8_t* __restrict__ img, typename Op::elem
     }
     *reinterpret_cast<typename Op::x8*>(out + m * Kp + ch * 8) = v;
   }
-}
-
-__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ pos, int B, int S, int E) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B * E) x[(size_t)(i / E) * S * E + (i % E)] = pos[i % E];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2178,8 +2177,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
-                       g.image_size, g.patch, g.grid(), Kp);
-    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * E + 255) / 256), dim3(256), 0, st, ws.x, w.pos, B, S, E);
+                       g.image_size, g.patch, g.grid(), Kp, ws.x, w.pos, S, E);
     const int Mp = B * P;
     GemmArgs a{ws.g, w.w_patch, Mp, E, Kp, w.b_patch, w.pos, ws.x, P, S, 0, 1.f / 256.f};
     const bool fits32 = (size_t)Mp * Kp < (1ull << 31);
