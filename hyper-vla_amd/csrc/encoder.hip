@@ -150,7 +150,7 @@ __device__ __forceinline__ f32x4 corr_value(f32x4 acc, float b) {
 // stays in this XCD's L2), so that another workgroup may read them inside this launch behind the stores' vmcnt(0), a
 // ticket and an agent-scope acquire (the LayerNorm tail of gemm256p_kernel) without a release fence, which would write
 // back the whole L2 once per tile (measured in round 2: 830 us per launch).
-template <typename Op, int EPI, int MT, bool FULL, bool ROWBIAS, bool CS = false, bool WT = false>
+template <typename Op, int EPI, int MT, bool FULL, bool ROWBIAS, bool CS = false, bool WT = false, bool NT = false>
 __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT], const GemmArgs& g, int m_base, int n_base,
                                                         int fr, int fq, const f32x4* pre_b4, const f32x4* pre_l4,
                                                         typename Op::x4* cs = nullptr,
@@ -189,7 +189,11 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
           if (ok[u][r]) xin[u][r] = *reinterpret_cast<const f32x4*>(g.aux + (uint32_t)prow * (uint32_t)g.N + (uint32_t)n);
         }
         if constexpr (EPI == EPI_RES) {
+#ifdef HVLA_EXP_NTRES
+          if (ok[u][r]) xin[u][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.out) + off[u][r]));
+#else
           if (ok[u][r]) xin[u][r] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.out) + off[u][r]);
+#endif
         }
         if constexpr (ROWBIAS) {
           brow[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -229,7 +233,13 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = (T)t[c][r];
           if constexpr (CS) *cs += o;                      // rows in ascending order: the order colmean_kernel restates
-          *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]) = o;
+          // NT (gemm256p_kernel on a big batch): q / k / v and the GELU outputs are read once, a kernel later, by other CUs
+          // (attention's loads are non-temporal too; fc2 fetches its A panels from the memory side anyway) -- kept out of L2 they
+          // leave the GEMM's own A / W panels there.  Same box, B = 256: QKV 2.52 -> 2.40, fc1 3.80 -> 3.72, fc2 3.31 -> 3.27 ms
+          // per step, the step 15.46 -> 15.25.  Small batches, whose outputs the next kernel finds in L2 / Infinity Cache, lose
+          // (B = 1: 1.246 -> 1.266 ms, B = 16: +0.4 %): the host asks for it from 96 MB of output on.
+          if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]));
+          else *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]) = o;
         } else if constexpr (EPI == EPI_RES) {
           f32x4 x = xin[u][r];
 #pragma unroll
@@ -1024,8 +1034,9 @@ __device__ unsigned long long g_lnt_dbg[4][256];
 #endif
 constexpr int LNT_SCRATCH = 98304, LNT_LDS = 163840, LNT_CTRL = LNT_LDS - 16;
 static_assert(LNT_SCRATCH + LNT_RED <= LNT_CTRL, "the tail's scratch ends below the control word");
-template <typename Op, int EPI, bool PERSIST, bool LNT = false>
+template <typename Op, int EPI, bool PERSIST, bool LNT = false, bool NTOUT = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
+  static_assert(!NTOUT || EPI == EPI_QKV || EPI == EPI_GELU, "non-temporal output stores: the 16-bit outputs only");
   using T = typename Op::elem;
   using X8 = typename Op::x8;
   static_assert(!LNT || EPI == EPI_RES || EPI == EPI_PATCH, "the LayerNorm tail follows a GEMM that writes the residual stream");
@@ -1226,7 +1237,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         typename Op::x4 csh;
 #pragma unroll
         for (int c = 0; c < 4; ++c) csh[c] = (T)0.f;
-        gemm_epilogue_rows_impl<Op, EPI, 8, true, false, true>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4, &csh);
+        gemm_epilogue_rows_impl<Op, EPI, 8, true, false, true, false, NTOUT>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4, &csh);
         typename Op::x4 mo;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1237,12 +1248,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         }
         if (fq == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.colmean) + ((size_t)ctm * 2 + wm) * g.N + cn0 + wn * 64 + 4 * fr) = mo;
       } else {
-        gemm_epilogue_rows_impl<Op, EPI, 8, true, false>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
+        gemm_epilogue_rows_impl<Op, EPI, 8, true, false, false, false, NTOUT>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
       }
     } else if constexpr (LNT) {
       gemm_epilogue_rows_impl<Op, EPI, 8, true, false, false, true>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
     } else {
-      gemm_epilogue_rows_impl<Op, EPI, 8, true, false>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
+      gemm_epilogue_rows_impl<Op, EPI, 8, true, false, false, false, NTOUT>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
     }
     if constexpr (LNT) {
       // ---- LayerNorm tail jobs.  Guide 6 G16 / "in-launch split-K reduction" in its write-through form: every wave's stores
@@ -1451,7 +1462,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * s4[j] + b4[j];
       if (FINAL) {
+#ifdef HVLA_EXP_NTTOK
+        __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + orow * E) + c);
+#else
         reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + orow * E)[c] = y;
+#endif
       } else {
         typename Op::x4 o;
 #pragma unroll
@@ -1664,7 +1679,11 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   const int q = wave * 32 + col;                           // always < S - 1
   X8 qf[4];
 #pragma unroll
+#ifdef HVLA_EXP_NTQ
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_nontemporal_load(reinterpret_cast<const X8*>(base + (size_t)q * rowstride + ks * 16 + half * 8));
+#else
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const X8*>(base + (size_t)q * rowstride + ks * 16 + half * 8);
+#endif
   // the extra query (token S-1) goes to LDS: 16 VGPRs less across the MFMA loops (the kernel runs at the 128-VGPR limit
   // of 4 waves per SIMD)
   if (tid < 8) *reinterpret_cast<X8*>(qxs + tid * 8) = *reinterpret_cast<const X8*>(base + (size_t)(S - 1) * rowstride + tid * 8);
@@ -2011,6 +2030,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm64_kernel<Op, EPI_QKV, 4>)) SETA((gemm64_kernel<Op, EPI_GELU, 4>)) SETA((gemm64_kernel<Op, EPI_RES, 4>))
     SETA((gemm64c_kernel<Op, EPI_QKV>)) SETA((gemm64c_kernel<Op, EPI_GELU>)) SETA((gemm64c_kernel<Op, EPI_RES>)) SETA((gemm64c32_kernel<Op>))
     SETA((gemm64c_kernel<Op, EPI_QKV, true>)) SETA((gemm64c_kernel<Op, EPI_GELU, true>))
+    SETA((gemm256p_kernel<Op, EPI_QKV, false, false, true>)) SETA((gemm256p_kernel<Op, EPI_GELU, false, false, true>))
+    SETA((gemm256p_kernel<Op, EPI_QKV, true, false, true>)) SETA((gemm256p_kernel<Op, EPI_GELU, true, false, true>))
 #undef SETA
     di.attr[opi] = true;
   }
@@ -2081,6 +2102,16 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
           ln_fused = true;
           return true;
         }
+      }
+      if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) {
+#ifndef HVLA_EXP_NOSTNT
+        if ((size_t)M * N * sizeof(T) >= ((size_t)96 << 20)) {       // a big batch: the 16-bit output goes past L2 (see the epilogue)
+          if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true, false, true>), dim3(ncu), dim3(512), lds, st, a);
+          else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false, false, true>), dim3(B * nbn), dim3(512), lds, st, a);
+          pf.end(cat, st);
+          return true;
+        }
+#endif
       }
       if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), lds, st, a);
       else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), lds, st, a);
