@@ -1,5 +1,5 @@
 cp hyper-vla_amd/lib/libhvla.so /tmp/libhvla_orig.so
-for rep in 1 2; do for v in BASE FENCE; do
+for rep in 1 2; do for v in "$@"; do
   cp tmp_variants/lib_$v.so hyper-vla_amd/lib/libhvla.so
   for b in 1 256; do python bench.py --batch $b --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
