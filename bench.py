@@ -348,14 +348,18 @@ def main():
     # policy-only variant (patch tokens resident -> actions), BASELINE config 2 "(P)"
     tokens = model.encode_images(images)
     torch.cuda.synchronize(dev)
-    for _ in range(3):
+    for _ in range(5):
         ctx.policy(w._h, tokens.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, stream)
     torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for _ in range(20):
+    # 100 back-to-back launches between two events on the launch stream (torch's current stream = model._stream()): a wall
+    # clock around 20 launches, as rounds 1-3 had it, adds the host's synchronisation to a 0.2 ms kernel (0.237 against 0.213 ms)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(100):
         ctx.policy(w._h, tokens.data_ptr(), actions.data_ptr(), logits.data_ptr(), B, stream)
+    e1.record(torch.cuda.current_stream(dev))
     torch.cuda.synchronize(dev)
-    pol_ms = (time.perf_counter() - t1) * 1e3 / 20
+    pol_ms = e0.elapsed_time(e1) / 100
 
     traffic = None                      # HBM bytes per launch of the dominant kernel: 2 * FETCH_SIZE + WRITE_SIZE
     try:                                # (gfx950 FETCH_SIZE counts half of a wide streaming read), from the
