@@ -60,7 +60,8 @@ struct hvla_ctx {
   DevBuf enc16, encd16, encf32;  // encoder matrices (16-bit), their rounding residues x 4096 (16-bit) and vectors (f32)
   EncWeights encw{};
   // workspaces (sized for cfg.max_batch)
-  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_corr, ws_abar, ws_lncnt, tokens, flags;
+  DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_corr, ws_abar, ws_lncnt, ws_lnpart, tokens, flags;
+  uint32_t ln_spin = 800;        // EncWorkspace::ln_spin (8 us); hvla_debug_lnx_spin of the bench library changes it
   Profiler prof;
   float *amap_dino = nullptr, *amap_head = nullptr;     // hvla_set_attention_outputs: caller-owned device buffers (opt-in)
   // cfg.streams == 2: helper stream and fork / join events of hvla_step
@@ -162,7 +163,8 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   A(ctx->ws_g, gbytes); A(ctx->tokens, Bm * P * E * 4); A(ctx->flags, 64 * sizeof(int));
   A(ctx->ws_corr, 2 * Bm * (F > 3 * E ? F : 3 * E) * 4);      // two rows per image (upper / lower half): encoder.hip GemmArgs::corr
   A(ctx->ws_abar, 2 * Bm * (F > E ? F : E) * 2);
-  A(ctx->ws_lncnt, (Bm + 4) * 4 + 64);                          // tickets of the LayerNorm tails, one per image (16-byte multiples per half batch)
+  A(ctx->ws_lncnt, (Bm + 4) * 4 + 64);                          // arrival words of the fused LayerNorms, one per image (16-byte multiples per half batch)
+  A(ctx->ws_lnpart, Bm * 4 * 256 * 2 * 4);                      // their per-row partial statistics: [image][column tile <= 4][256][2] f32
   if (e != hipSuccess) return HVLA_E_ARENA_FULL;
   if (hipMemset(ctx->ws_lncnt.p, 0, ctx->ws_lncnt.bytes) != hipSuccess) return HVLA_E_HIP;
   if (c->streams == 2) {
@@ -501,7 +503,9 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
                   ctx->ws_corr.as<float>() + (size_t)2 * b0 * (F > 3 * E ? F : 3 * E),
                   static_cast<char*>(ctx->ws_abar.p) + (size_t)2 * b0 * (F > E ? F : E) * 2};
   if (ctx->amap_dino) ws.amap = ctx->amap_dino + (size_t)b0 * g.enc_layers * g.enc_heads * g.P();
-  if (ctx->cfg.layernorm_tail) ws.ln_cnt = ctx->ws_lncnt.as<uint32_t>() + (size_t)((b0 + 3) / 4 * 4);   // (a second half starts on a 16-byte boundary)
+  ws.ln_cnt = ctx->ws_lncnt.as<uint32_t>() + (size_t)((b0 + 3) / 4 * 4);   // (a second half starts on a 16-byte boundary)
+  ws.ln_part = ctx->ws_lnpart.as<float>() + (size_t)b0 * 4 * 256 * 2;
+  ws.ln_spin = ctx->ln_spin;
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
                              &ctx->prof, keep_cls));
@@ -538,7 +542,7 @@ int hvla_encode_audit(hvla_ctx* ctx, const uint8_t* images, int32_t B, float* ma
   const size_t F = g.enc_mlp, E = g.E;
   EncWorkspace ws{ctx->ws_x.as<float>(), ctx->ws_h.p, ctx->ws_qkv.p, ctx->ws_g.p, ctx->ws_corr.as<float>(), ctx->ws_abar.p};
   (void)F; (void)E;
-  if (ctx->cfg.layernorm_tail) ws.ln_cnt = ctx->ws_lncnt.as<uint32_t>();
+  ws.ln_cnt = ctx->ws_lncnt.as<uint32_t>(); ws.ln_part = ctx->ws_lnpart.as<float>(); ws.ln_spin = ctx->ln_spin;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images, ctx->tokens.as<float>(), B, st, nullptr, false, slots));
   uint32_t h[8];
   HIPCHK(ctx, hipMemcpyAsync(h, slots, sizeof h, hipMemcpyDeviceToHost, st));
@@ -978,10 +982,17 @@ int hvla_debug_train_gemm_exact(int on) {
 }
 // shader-clock stamps of the last context-encoder launch (workgroup 0): see hypernet.hip CTX_STAMP
 int hvla_debug_ctx_stamps(unsigned long long* out) { return debug_ctx_stamps(out) == hipSuccess ? HVLA_OK : HVLA_E_HIP; }
-int hvla_debug_lnt_stats(hvla_ctx* ctx, unsigned long long* out, int reset) {
+int hvla_debug_lnx_stats(hvla_ctx* ctx, unsigned long long* out, int reset) {
   if (!ctx) return HVLA_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, debug_lnt_stats(out, reset));
+  HIPCHK(ctx, debug_lnx_stats(out, reset));
+  return HVLA_OK;
+}
+// how long a column tile of a residual GEMM waits for the image's other tiles (ticks of 10 ns; the product's value is 800).  0 = nobody
+// waits: every tile but an image's last arriver is normalised from memory -- the test that the two routes give the same bytes
+int hvla_debug_lnx_spin(hvla_ctx* ctx, uint32_t ticks) {
+  if (!ctx) return HVLA_E_STATE;
+  ctx->ln_spin = ticks;
   return HVLA_OK;
 }
 #endif  // HVLA_BENCH_HOOKS

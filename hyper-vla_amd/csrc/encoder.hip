@@ -108,17 +108,28 @@ struct GemmArgs {
   // GEMM's contiguous rows: 0, 256); nbm tile rows, every tile full
   int tile_row0 = 0, tile_stride = 256, nbm = 0;
   void* colmean = nullptr;       // GELU, image-aligned tiles only: [B][2][N] 16-bit mean over each wave row's 128 rows of its rounded outputs
-  // gemm256p_kernel<..., LNT = true> (RES / PATCH on image-aligned tiles): the LayerNorm that follows this GEMM as its TAIL.
-  // out is the f32 residual stream x [B*S][N] (N = E); its stores go through to memory (sc1), every tile draws a ticket
-  // from ln_cnt[image], and the workgroup that draws the image's last one normalises the image's S rows -> ln_out (16-bit)
-  // and writes the two mean rows -> ln_abar (nullable), with ln_row()'s arithmetic and layernorm_img_kernel's order of
-  // additions: the same bits as the stand-alone LayerNorm launch it replaces.
+  // gemm256p_kernel<..., LNX = true> (RES / PATCH on image-aligned tiles): the LayerNorm that follows this GEMM (norm1 / norm2,
+  // base_vit.py:109-122 -> HF Dinov2Layer) inside its epilogue -- nobody reads x again.  Every column tile of an image keeps its
+  // 256 x 256 block of the new residual stream in the dead accumulators, publishes per-row (sum, sum of squares) over its 256
+  // columns to ln_part, counts itself in ln_cnt[image], waits for the image's other column tiles (same round, same XCD: a few
+  // microseconds of skew), combines the partials in column-tile order and normalises from registers -> ln_out (16-bit) and the
+  // two mean rows -> ln_abar.  A tile whose partners are not due soon (another round of a persistent grid, or the bound ln_spin
+  // ran out) does not wait: it marks itself abandoned in the image's word and goes on; the image's last arriver then normalises
+  // that tile too, from the x the abandoner stored (write-through).  Same bits either way, and nothing can hang.
   void* ln_out = nullptr;        // 16-bit [B*S][N]
   const float* ln_scale = nullptr;
   const float* ln_bias = nullptr;
-  void* ln_abar = nullptr;       // 16-bit [B][2][N]
-  uint32_t* ln_cnt = nullptr;    // [B] tickets, zero between launches (the last arriver puts the zero back)
+  void* ln_abar = nullptr;       // 16-bit [B][2][N] (nullable)
+  uint32_t* ln_cnt = nullptr;    // [B]: bits 0-15 column tiles arrived since the call's memset (ln_target = launch number x nbn),
+                                 //      bit 16 + c: column tile c of this launch was abandoned
+  float* ln_part = nullptr;      // [B][nbn][256][2] f32
+  uint32_t ln_target = 0;
+  uint32_t ln_spin = 0;          // bound of the wait, in ticks of the 100 MHz constant clock
   uint32_t out_bytes = 0;        // size of `out` in bytes (buffer descriptor of the write-through stores)
+  uint32_t part_bytes = 0;       // size of ln_part in bytes
+  // persistent form (tile_origin_x): G = workgroups per XCD label / nbn, rows_aligned = rounds x G, rounds_div = rounds / nbn,
+  // rows_xcd = images per XCD label, rcp = ceil(65536 / nbn)
+  int lnx_G = 0, lnx_rows_aligned = 0, lnx_rounds_div = 0, lnx_rows_xcd = 0, lnx_rcp = 0;
   // gemm64c_kernel<..., FOLD = true> (the GEMM behind a LayerNorm at a small batch): the mean rows are not read from abar2 but
   // added up by every workgroup from layernorm_split_kernel's partial column sums [image][half][LNW][K] f32, with
   // layernorm_mean_kernel's arithmetic -- that launch (two per layer, 4.5 us + a kernel boundary each at B = 1) is gone
@@ -216,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
       f32x4 t[4];                                    // [column c] over the four rows r: the accumulators' own register pairs
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if constexpr (EPI == EPI_PATCH) t[c] = acc[c][mp + u] * q + b4[c];      // patch weights are stored x256 (16-bit range)
+        if constexpr (EPI == EPI_PATCH) t[c] = __builtin_elementwise_fma(acc[c][mp + u], f32x4{q, q, q, q}, f32x4{b4[c], b4[c], b4[c], b4[c]});   // patch weights are stored x256 (16-bit range)
         else if constexpr (EPI == EPI_CORR) t[c] = corr_value(acc[c][mp + u], b4[c]);
         else if constexpr (ROWBIAS) t[c] = acc[c][mp + u] + f32x4{brow[u][0][c], brow[u][1][c], brow[u][2][c], brow[u][3][c]};
         else t[c] = acc[c][mp + u] + b4[c];
@@ -480,7 +491,10 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
 // that the epilogue reads instead of a table in memory: the separate table launch in front of every GEMM (48 per step,
 // 12 us each at B = 1) is gone.  Same operands, same MFMA, same k order as gemm64_body<EPI_CORR> => the same bias rows.
 constexpr int SNSC = 5, SSTC = 28672;   // stages x (A 8 KB | W 8 KB | dW 8 KB | mean rows 4 KB)
-constexpr int LNW = 16;                 // waves of layernorm_img_kernel = workgroups per image of layernorm_split_kernel = partials per mean row
+constexpr int LNW = 16;                 // waves of a LayerNorm workgroup
+constexpr int LNG = 8;                  // row groups per image of layernorm_group_kernel = partial column sums per image: [half][fq]
+// abar[(image, half)] = ((p0 + p1) + (p2 + p3)) / (P / 2): the four partials of a half (layernorm_group_kernel), n4 float4 apart
+__device__ __forceinline__ f32x4 ln_half_sum(const f32x4* p, int n4) { return (p[0] + p[n4]) + (p[2 * n4] + p[3 * n4]); }
 // FOLD: the mean rows of ALL K-tiles sit in a table behind the stages ([K-tile][16 rows][128 B], a stage's mean-row image), written
 // once in the prologue from the LayerNorm's partial sums (GemmArgs::ln_partial); a stage is then A | W | dW = 24 KB, six pieces.
 constexpr int SSTF = 24576;
@@ -558,14 +572,8 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
     const int n4 = g.K / 4;
     for (int it = tid; it < nr * n4; it += 256) {
       const int r = it / n4, c4 = it - r * n4, bh = img0 * 2 + r;
-      const f32x4* pp = reinterpret_cast<const f32x4*>(g.ln_partial + (size_t)bh * LNW * g.K) + c4;
-      f32x4 pv[LNW];
-#pragma unroll
-      for (int w = 0; w < LNW; ++w) pv[w] = pp[w * n4];
-      f32x4 t = pv[0];
-#pragma unroll
-      for (int w = 1; w < LNW; ++w) t += pv[w];
-      const float inv = 1.f / (float)((bh & 1) ? g.S - g.hsplit : g.hsplit);
+      const f32x4 t = ln_half_sum(reinterpret_cast<const f32x4*>(g.ln_partial + (size_t)bh * 4 * g.K) + c4, n4);
+      const float inv = 1.f / (float)(g.P / 2);
       typename Op::x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (T)(t[j] * inv);
@@ -833,171 +841,126 @@ __device__ __forceinline__ float wave64_sum(float v) {
   return (lane_bcast(t, 0) + lane_bcast(t, 16)) + (lane_bcast(t, 32) + lane_bcast(t, 48));
 }
 
-// one row: statistics (f32, two passes over the registers), the f32 outputs y (what the column sums add) and the 16-bit store.
-// Shared by the one-workgroup-per-image kernel and the split form below, so that a row and its contribution to the mean row
-// are the same bits in both.
-// NCH: 64-lane chunks of four columns a row is held in (4 covers E <= 1024; the LayerNorm tail of gemm256p_kernel uses 3 for
-// E <= 768 to have registers for more rows in flight: an absent chunk only ever contributed + 0.0f).
-// FULLCH: n4 == 64 * NCH, every chunk is full -- no per-chunk predicate (the predicates are divergent branches to the compiler,
-// and behind their joins it waits vmcnt(0) for every load in flight: the tail's row prefetch needs the branch-free form).
-template <typename Op, int NCH = 4, bool FULLCH = false, typename OutPtr = typename Op::elem*>
-__device__ __forceinline__ void ln_row(const f32x4 (&cur)[NCH], const f32x4 (&s4)[NCH], const f32x4 (&b4)[NCH], int n4, float invE, int lane,
-                                       OutPtr orow, f32x4 (&y)[NCH]) {     // invE = 1.f / E (one multiply instead of an IEEE division per statistic)
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
-  sum = wave64_sum(sum);
-  const float mean = sum * invE;
-  float sq = 0.f;
+// ---- the CANONICAL arithmetic of norm1 / norm2 (HF Dinov2Layer.norm1 / .norm2 as called at base_vit.py:109-122; flax
+// nn.LayerNorm, eps 1e-6, one-pass statistics E[x^2] - E[x]^2 clipped at 0: SURVEY.md Appendix A).  Round 5: the LayerNorm
+// behind a residual GEMM runs inside that GEMM's epilogue (gemm256p_kernel<..., LNX>) on the accumulator layout, where a row's
+// E columns are spread over column tiles (workgroups), waves and lanes; the stand-alone kernels (small batches, the CLS rows,
+// geometries without image-aligned tiles) restate the same additions in the same order, so that a row of h and a mean row are
+// the same bits whichever kernel wrote them (the batch-invariance tests cross them):
+//   * a lane holds four consecutive columns v[0..3]:  s = (v0 + v1) + (v2 + v3),  q = fma(v1, v1, v0 v0) + fma(v3, v3, v2 v2);
+//   * 16 lanes = 64 columns (a wave's columns of a GEMM tile / a 16-lane row of a 64-lane chunk): the DPP tree of row16_sum;
+//   * four such groups = 256 columns (a GEMM column tile / a 64-lane chunk of four columns per lane): (g0 + g1) + (g2 + g3);
+//   * the 256-column blocks in ascending order; columns past E count as zeros;
+//   * mean = S / E as S * (1 / E), var = max(fma(Q, 1 / E, -(mean mean)), 0), rstd = rsqrt(var + 1e-6),
+//     y = fma((x - mean) rstd, scale, bias), h = y rounded to the operand type;
+//   * mean rows (the operand of the next GEMM's weight-rounding compensation): one per image HALF over its P / 2 patch rows
+//     (the CLS row is left out, as in colmean_kernel and attention_kernel), f32 sums of y: row 16 mt + 4 fq + r of the half
+//     goes to partial fq, each partial adds its rows in ascending order, the half is (p0 + p1) + (p2 + p3), x 1 / (P / 2),
+//     rounded to the operand type.
+__device__ __forceinline__ void ln_lane_stats(f32x4 v, float& s, float& q) {
+  s = (v[0] + v[1]) + (v[2] + v[3]);
+  q = fmaf(v[1], v[1], v[0] * v[0]) + fmaf(v[3], v[3], v[2] * v[2]);
+}
+__device__ __forceinline__ void ln_finish(float S, float Q, float invE, float& mean, float& rstd) {
+  mean = S * invE;
+  const float var = fmaxf(fmaf(Q, invE, -(mean * mean)), 0.f);
+  rstd = rsqrtf(var + 1e-6f);
+}
+__device__ __forceinline__ float ln_value(float x, float mean, float rstd, float sc, float bi) { return fmaf((x - mean) * rstd, sc, bi); }
+
+// a whole row held by ONE wave as NCH 64-lane chunks of four columns per lane (lane l of chunk i: columns 256 i + 4 l ..):
+// statistics in the canonical order, the same value in every lane
+template <int NCH>
+__device__ __forceinline__ void ln_row_stats(const f32x4 (&cur)[NCH], float invE, float& mean, float& rstd) {
+  float S = 0.f, Q = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    if (FULLCH || lane + 64 * i < n4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float d = cur[i][j] - mean;
-        sq += d * d;
-      }
-    }
+    float s, q;
+    ln_lane_stats(cur[i], s, q);
+    s = row16_sum(s);
+    q = row16_sum(q);
+    const float cs = (lane_bcast(s, 0) + lane_bcast(s, 16)) + (lane_bcast(s, 32) + lane_bcast(s, 48));
+    const float cq = (lane_bcast(q, 0) + lane_bcast(q, 16)) + (lane_bcast(q, 32) + lane_bcast(q, 48));
+    S = i ? S + cs : cs;
+    Q = i ? Q + cq : cq;
   }
-  sq = wave64_sum(sq);
-  const float rstd = rsqrtf(sq * invE + 1e-6f);
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int col = lane + 64 * i;
-    y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (FULLCH || col < n4) {
-      typename Op::x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        y[i][j] = (cur[i][j] - mean) * rstd * s4[i][j] + b4[i][j];
-        o[j] = (typename Op::elem)y[i][j];
-      }
-      if constexpr (std::is_same<OutPtr, typename Op::elem*>::value) reinterpret_cast<typename Op::x4*>(orow)[col] = o;
-      else ((__attribute__((address_space(1))) typename Op::x4*)orow)[col] = o;
-    }
-  }
+  ln_finish(S, Q, invE, mean, rstd);
 }
 
-
-// The LayerNorm that follows a residual GEMM (norm1 / norm2) as a TAIL JOB of gemm256p_kernel: run by a workgroup that has
-// claimed image `img` after every column tile of the image's 256 patch rows has stored its part of x write-through and
-// drained (the CLS row was finished by an earlier launch).  Eight waves; wave w plays the "waves" w and w + 8 of
-// layernorm_img_kernel (rows w, w + 16, ... and w + 8, w + 24, ...: separate column sums A / B), ln_row() is the same function,
-// and the sixteen partial column sums are added in that kernel's order -- so the 16-bit rows and the two mean rows are the
-// bits the stand-alone launch would have written.  D rows per wave are in flight (the reads come from the memory side, ~2 us
-// away under load: 8 waves x 8 rows x 3 KB); the two rows of a pair (one A, one B) are normalised in ONE basic block so that
-// the scheduler interleaves their dependent reduction chains (the tail is bound by VALU issue, two waves per SIMD).
-// S = 257 (image-aligned tiles only exist for 256 patches).  lds: LNT_RED bytes of scratch for the sums.
-constexpr int LNT_CW = 192;                    // float4 columns per pass of the mean-row sums: [16][LNT_CW] float4 = 48 KB
-constexpr int LNT_RED = 16 * LNT_CW * 16;
-// Inlined.  (As a real call -- noinline, a register allocation of its own -- the tail was 3 us slower per job: its callee-saved
-// registers go to scratch and back on every call, 188 scratch operations; inlined with FOUR rows per block the one allocation
-// problem of the whole kernel answered with 49 spills inside the K loops.  Two rows per block and an opaque copy of the thread id
-// at the call site keep the K loops clean: tools/kernel_resources.sh.)
-typedef __attribute__((address_space(3))) char lds_char;
-template <typename Op, int NCH, bool FULLCH>
-__device__ __forceinline__ void ln_tail(const float* x, typename Op::elem* out, const float* ln_scale, const float* ln_bias,
-                                                 typename Op::elem* abar, int S, int E, int hsplit, lds_char* lds, int wave, int tid) {
-  using T = typename Op::elem;
-  // a callee's pointer arguments are generic to the compiler (flat_load / flat_store, counted on vmcnt AND lgkmcnt: every wait
-  // becomes a full drain); they are global memory
-  typedef const __attribute__((address_space(1))) f32x4 g_cf32x4;
-  typedef __attribute__((address_space(1))) typename Op::x4 g_x4;
-  typedef __attribute__((address_space(1))) typename Op::elem g_elem;
-  const int lane = tid & 63;
-  const int n4 = E / 4;
+// Stand-alone norm1 / norm2 (+ the partial column sums of the mean rows): grid (8, B), workgroup (image b, group g = half * 4 + fq)
+// normalises the 4 nmt rows  token 1 + half P/2 + 16 mt + 4 fq + r  (index i = 4 mt + r, ascending = the order partial fq adds
+// them in), wave w the indices w, w + 16, ...; their y go to LDS and one thread per four columns adds them in index order ->
+// partial[b][g][E] f32.  Group 0 also normalises the CLS row (token 0; in no mean row).  layernorm_mean_kernel (or the consumer
+// GEMM itself: gemm64c_kernel<..., FOLD>) then combines (p0 + p1) + (p2 + p3) per half.  E % 4 == 0, E <= 1024, P % 32 == 0.
+template <typename Op>
+__global__ __launch_bounds__(LNW * 64) void layernorm_group_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
+                                                                   const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                   float* __restrict__ partial, int S, int P, int E) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* ys = reinterpret_cast<f32x4*>(smem);                        // [4 nmt][E / 4]
+  const int grp = blockIdx.x, b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n4 = E / 4, nrows = P / 8;                               // rows of a group = 4 nmt = 4 (P / 2) / 16
+  const int tok0 = 1 + (grp >> 2) * (P / 2) + 4 * (grp & 3);
   const float invE = 1.f / (float)E;
-  f32x4 s4[NCH], b4[NCH], csA0[NCH], csA1[NCH], csB0[NCH], csB1[NCH];
-  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 s4[4], b4[4];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int col = lane + 64 * i;
-    csA0[i] = csA1[i] = csB0[i] = csB1[i] = z4;
-    s4[i] = (FULLCH || col < n4) ? ((g_cf32x4*)ln_scale)[col] : z4;
-    b4[i] = (FULLCH || col < n4) ? ((g_cf32x4*)ln_bias)[col] : z4;
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    s4[i] = col < n4 ? reinterpret_cast<const f32x4*>(scale)[col] : z;
+    b4[i] = col < n4 ? reinterpret_cast<const f32x4*>(bias)[col] : z;
   }
+  const int nwork = nrows + (grp == 0 ? 1 : 0);                      // index nrows (group 0 only) = the CLS row
+  for (int i = wave; i < nwork; i += LNW) {                          // wave-uniform
+    const int tok = i < nrows ? tok0 + 16 * (i >> 2) + (i & 3) : 0;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((size_t)b * S + tok) * E);
+    f32x4 cur[4];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(s4[i]), "+v"(b4[i]));      // waited for here, not inside the row loop
-  constexpr int D = NCH <= 3 ? 8 : 4;          // rows in flight per wave (even: row d of a group is A for even d, B for odd d)
-  f32x4 buf[D][NCH];
-  auto load = [&](f32x4 (&v)[NCH], int row) {
-    g_cf32x4* xr = (g_cf32x4*)(x + (size_t)(row < S ? row : S - 1) * E);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int col = lane + 64 * i;
-      if constexpr (FULLCH) v[i] = xr[col];
-      else {                                   // the load itself is unconditional (a valid address), the zero a select
-        const f32x4 t = xr[col < n4 ? col : n4 - 1];
-        v[i] = col < n4 ? t : z4;
-      }
+    for (int c = 0; c < 4; ++c) {
+      const int col = lane + 64 * c;
+      cur[c] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  };
+    float mean, rstd;
+    ln_row_stats<4>(cur, invE, mean, rstd);
+    typename Op::elem* orow = out + ((size_t)b * S + tok) * E;
 #pragma unroll
-  for (int d = 0; d < D; ++d) load(buf[d], wave + 8 * d);
-  constexpr int G = 2;                         // rows normalised per basic block: their reduction chains are independent, the scheduler interleaves them
-  static_assert(D % G == 0 && G % 2 == 0, "a group is whole A / B pairs of the rows in flight");
-  for (int i0 = 0; i0 < 32; i0 += D) {         // rows wave + 8 i, i < 32: rows 0 .. 255
-#pragma unroll
-    for (int d0 = 0; d0 < D; d0 += G) {
-      f32x4 y[G][NCH];
-#pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const int row = wave + 8 * (i0 + d0 + u);
-        ln_row<Op, NCH, FULLCH, g_elem*>(buf[d0 + u], s4, b4, n4, invE, lane, (g_elem*)(out + (size_t)row * E), y[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < G; ++u) load(buf[d0 + u], wave + 8 * (i0 + d0 + u + D));   // (past the end: the last row again, unused)
-#pragma unroll
-      for (int u = 0; u < G; ++u) {            // ascending rows per virtual wave: A = even u, B = odd u
-        const int row = wave + 8 * (i0 + d0 + u);
-        if (row < hsplit) {                    // wave-uniform
-#pragma unroll
-          for (int i = 0; i < NCH; ++i)
-            if (u & 1) csB0[i] += y[u][i]; else csA0[i] += y[u][i];
-        } else {
-#pragma unroll
-          for (int i = 0; i < NCH; ++i)
-            if (u & 1) csB1[i] += y[u][i]; else csA1[i] += y[u][i];
-        }
-      }
-    }
-  }
-  if (wave == 0) {                             // row 256 = the last row of "wave 0" (buf[0] holds it: row 0 + 8 * 32)
-    f32x4 y[NCH];
-    ln_row<Op, NCH, FULLCH, g_elem*>(buf[0], s4, b4, n4, invE, lane, (g_elem*)(out + (size_t)(S - 1) * E), y);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) csA1[i] += y[i];
-  }
-  if (!abar) return;                           // (uniform over the workgroup)
-  typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-  lds_f32x4* red = reinterpret_cast<lds_f32x4*>(lds);   // [16][LNT_CW]
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    for (int c0 = 0; c0 < n4; c0 += LNT_CW) {  // one pass at E <= 768
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int col = lane + 64 * i - c0;
-        if (col >= 0 && col < LNT_CW && col + c0 < n4) {
-          red[wave * LNT_CW + col] = hf ? csA1[i] : csA0[i];
-          red[(wave + 8) * LNT_CW + col] = hf ? csB1[i] : csB0[i];
-        }
-      }
-      __syncthreads();
-      if (tid < LNT_CW && c0 + tid < n4) {
-        f32x4 t = red[tid];
-#pragma unroll
-        for (int w = 1; w < LNW; ++w) t += red[w * LNT_CW + tid];
-        const float inv = 1.f / (float)(hf ? S - hsplit : hsplit);
+    for (int c = 0; c < 4; ++c) {
+      const int col = lane + 64 * c;
+      if (col < n4) {
+        f32x4 y;
         typename Op::x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (T)(t[j] * inv);
-        ((g_x4*)(abar + (size_t)hf * E))[c0 + tid] = o;
+        for (int j = 0; j < 4; ++j) {
+          y[j] = ln_value(cur[c][j], mean, rstd, s4[c][j], b4[c][j]);
+          o[j] = (typename Op::elem)y[j];
+        }
+        reinterpret_cast<typename Op::x4*>(orow)[col] = o;
+        if (partial && i < nrows) ys[i * n4 + col] = y;
       }
     }
   }
+  if (!partial) return;
+  __syncthreads();
+  if ((int)threadIdx.x < n4) {
+    f32x4 cs = ys[threadIdx.x];
+    for (int i = 1; i < nrows; ++i) cs += ys[i * n4 + threadIdx.x];
+    reinterpret_cast<f32x4*>(partial + ((size_t)b * LNG + grp) * E)[threadIdx.x] = cs;
+  }
 }
-
+// abar[(image, half)] = ((p0 + p1) + (p2 + p3)) / (P / 2), rounded to the operand type
+template <typename Op>
+__global__ __launch_bounds__(256) void layernorm_mean_kernel(const float* __restrict__ partial, typename Op::elem* __restrict__ abar,
+                                                             int P, int E) {
+  const int bh = blockIdx.x, n4 = E / 4;                             // (image, half)
+  if ((int)threadIdx.x >= n4) return;
+  const f32x4 t = ln_half_sum(reinterpret_cast<const f32x4*>(partial + (size_t)bh * 4 * E) + threadIdx.x, n4);
+  const float inv = 1.f / (float)(P / 2);
+  typename Op::x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (typename Op::elem)(t[j] * inv);
+  reinterpret_cast<typename Op::x4*>(abar + (size_t)bh * E)[threadIdx.x] = o;
+}
 // ------------------------------------------------------------------------------------------------
 // gemm256p_kernel -- the production GEMM.  256x256x64 block tiles, 8 waves (2 along M x 4 along N, 128x64 each), operands
 // staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction).  The LDS
@@ -1024,23 +987,24 @@ constexpr int PRO_DMA = 12, PRO_DMA_KT0 = 8;        // LDS-DMA instructions per 
 // loads, stores and DMA together and retires in order): MT = 8 m-tiles x 4 rows of stores, plus as many residual loads.
 template <int EPI> struct EpiVmem { static constexpr int min_ops = (EPI == EPI_RES || EPI == EPI_PATCH) ? 64 : 32; };
 
-// LNT (RES / PATCH, image-aligned tiles): the LayerNorm behind this GEMM runs as its tail -- GemmArgs::ln_*, ln_tail().  The
-// launch then asks for 160 KB of LDS: the tail's scratch starts at LNT_SCRATCH = the W half of buffer 1, which the next tile's
-// prologue DMA (already in flight during the epilogue) does not touch, and runs into the 32 KB behind the buffers; the last
-// 16 bytes are the word through which wave 0 tells the workgroup which image it claimed.
+// LNX (RES / PATCH, image-aligned tiles): the LayerNorm behind this GEMM inside its epilogue (GemmArgs::ln_*).  Its LDS -- the
+// four waves' row statistics, (mean, rstd) per row, a control word -- lies in the W half of buffer 1, which the next tile's
+// prologue DMA (in flight during the epilogue) does not touch and nobody stages before phase 1 of the next K loop.
 #ifdef HVLA_BENCH_HOOKS
-// libhvla_bench.so (tools/lnt_stats.py): per workgroup id, summed over the launches since the last reset:
-// [0] tail jobs done, [1] shader-clock ticks inside tail jobs, [2] ticks from the drain to "job known", [3] launches
-__device__ unsigned long long g_lnt_dbg[4][256];
+// libhvla_bench.so (tools/lnx_stats.py): per workgroup id, summed over the launches since the last reset: [0] tiles, [1] shader-clock
+// ticks of the whole epilogue, [2] ticks between "partials published" and "partners known", [3] tiles abandoned, [4] tiles
+// normalised from memory by the image's last arriver, [5] ticks of [A] (x into registers), [6] of [B] (statistics, publish, drain),
+// [7] of [D] + [E] (+ [F]) (mean / rstd, normalise, store h)
+__device__ unsigned long long g_lnx_dbg[8][256];
 #endif
-constexpr int LNT_SCRATCH = 98304, LNT_LDS = 163840, LNT_CTRL = LNT_LDS - 16;
-static_assert(LNT_SCRATCH + LNT_RED <= LNT_CTRL, "the tail's scratch ends below the control word");
-template <typename Op, int EPI, bool PERSIST, bool LNT = false, bool NTOUT = false>
+constexpr int LNX_STAT = 98304, LNX_MR = LNX_STAT + 8192, LNX_CTRL = LNX_MR + 2048;   // [4][256][2] f32 | [256][2] f32 | 16 B
+typedef __attribute__((address_space(3))) char lds_char;
+template <typename Op, int EPI, bool PERSIST, bool LNX = false, bool NTOUT = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
-  static_assert(!NTOUT || (EPI != EPI_PATCH && !LNT), "NTOUT: non-temporal stores of the 16-bit outputs (QKV, GELU) / loads of the residual rows (RES)");
+  static_assert(!NTOUT || EPI != EPI_PATCH, "NTOUT: non-temporal stores of the 16-bit outputs (QKV, GELU) / loads of the residual rows (RES)");
   using T = typename Op::elem;
   using X8 = typename Op::x8;
-  static_assert(!LNT || EPI == EPI_RES || EPI == EPI_PATCH, "the LayerNorm tail follows a GEMM that writes the residual stream");
+  static_assert(!LNX || EPI == EPI_RES || EPI == EPI_PATCH, "the fused LayerNorm follows a GEMM that writes the residual stream");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 buffers x (A 32 KB | W 32 KB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1063,8 +1027,32 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     tm = chunk * CH + r2 / GN;
     n0 = (sc * GN + r2 % GN) * HBN_;
   };
+  // LNX, persistent: the nbn column tiles of an image must run in the SAME round (they wait for each other's row statistics).
+  // An XCD label (blockIdx % 8) has Wx = gridDim / 8 workgroups and nbm / 8 images; its first G nbn workgroups (G = Wx / nbn) form
+  // G groups, group k takes image r G + k in round r, one column tile per member.  The Wx % nbn workgroups that are left over
+  // (two of 32 at nbn = 3) take one image each per nbn rounds, its column tiles one after the other: all but the last of those
+  // tiles are `later` -- abandoned at once (GemmArgs::ln_cnt) and normalised from memory when the last one is done.  The host
+  // only asks for this form when the counts divide (run_encoder).
+  // (no division here: the quotients by nbn go through the host's reciprocal GemmArgs::lnx_rcp = ceil(65536 / nbn), exact for the
+  // few dozen workgroups per XCD / rounds there are; G, R / nbn and the images per XCD label come from the host as well)
+  bool later = false;
+  int rnd = 0;                                       // tiles this workgroup has started
+  auto tile_origin_x = [&](int& tm, int& n0, bool& lat) {
+    const int xcd = (int)blockIdx.x & 7, w = (int)blockIdx.x >> 3;
+    const int G = g.lnx_G, wq = (w * g.lnx_rcp) >> 16, rq = (rnd * g.lnx_rcp) >> 16;
+    int row, col;
+    if (wq < G) {
+      row = rnd * G + wq; col = w - wq * nbn; lat = false;
+    } else {
+      row = g.lnx_rows_aligned + (w - G * nbn) * g.lnx_rounds_div + rq; col = rnd - rq * nbn; lat = col != nbn - 1;
+    }
+    tm = xcd * g.lnx_rows_xcd + row;
+    n0 = col * HBN_;
+    ++rnd;
+  };
   int vb = blockIdx.x, tm, n0;
-  tile_origin(vb, tm, n0);
+  if constexpr (LNX && PERSIST) tile_origin_x(tm, n0, later);
+  else tile_origin(vb, tm, n0);
   int m0 = g.tile_row0 + tm * g.tile_stride;       // first global row of the tile
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
@@ -1181,9 +1169,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
-  if constexpr (LNT) {            // tail jobs this workgroup has done: a word of LDS, not a register across the K loops (read
-    if (tid == 0) reinterpret_cast<volatile int*>(smem + LNT_CTRL)[1] = 0;    // by wave 0 behind dozens of barriers)
-  }
   while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1198,6 +1183,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       ktile(kt, No{}, No{});
     }
     if (wm == 0) HVLA_BAR();                          // same number of barriers in both wave rows
+    if constexpr (LNX) {
+      // the accumulators start new live ranges here: the register allocator then treats the K loop (at the register limit) and the
+      // long epilogue below separately (without this it spilled four accumulator tiles INSIDE the last K-tile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[i][j]));
+    }
     const int cm0 = m0, cn0 = n0, ctm = tm;
     bool more = false;
     // bias row (per image when a corr table is given: an image-aligned tile row IS an image) / LayerScale of this tile
@@ -1213,11 +1206,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       if constexpr (EPI == EPI_RES) pl4 = *reinterpret_cast<const f32x4*>(g.aux + vcol);
     }
     asm volatile("" : "+v"(pb4), "+v"(pl4));
+    const bool clater = later;
     if constexpr (PERSIST) {
       vb += gridDim.x;
       more = vb < ntiles;
       if (more) {
-        tile_origin(vb, tm, n0);
+        if constexpr (LNX) tile_origin_x(tm, n0, later);
+        else tile_origin(vb, tm, n0);
         m0 = g.tile_row0 + tm * g.tile_stride;
         abase = A + (size_t)m0 * g.K;
         wbase = W + (size_t)n0 * g.K;
@@ -1228,7 +1223,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);            // nothing may be scheduled across it in either direction
       }
     }
-    if (!wvalid) {
+    if constexpr (LNX) {
+      // (below)
+    } else if (!wvalid) {
       // nothing to store
     } else if constexpr (EPI == EPI_GELU) {
       if (g.colmean) {
@@ -1251,152 +1248,329 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       } else {
         gemm_epilogue_rows_impl<Op, EPI, 8, true, false, false, false, NTOUT>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
       }
-    } else if constexpr (LNT) {
-      gemm_epilogue_rows_impl<Op, EPI, 8, true, false, false, true>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
     } else {
       gemm_epilogue_rows_impl<Op, EPI, 8, true, false, false, false, NTOUT>(acc, g, cm0 + wm * 128, cn0 + wn * 64, fr, fq, &pb4, &pl4);
     }
-    if constexpr (LNT) {
-      // ---- LayerNorm tail jobs.  Guide 6 G16 / "in-launch split-K reduction" in its write-through form: every wave's stores
-      // of x have reached the memory side (vmcnt(0); also: the next tile's prologue DMA has landed), the workgroup's barrier,
-      // ONE lane adds the image's ticket (relaxed, agent scope).  ln_cnt[image]: bits 0-7 count the arrived column tiles; all
-      // nbn arrived = every tile of the image is in memory and the image belongs to its last arriver, which either normalises
-      // it at once or PUBLISHES it (LNT_FREE) for another workgroup to claim (compare-and-swap back to nbn); 0 again when its
-      // tail is done.  Whoever normalises an image acquires first (buffer_inv sc1: this CU's L1; its wait is in front of the
-      // barrier that lets the other waves read) and reads the rows with plain loads.  Which workgroup, CU or XCD ran the image's
-      // tiles, and which one normalises it, does not matter for the result.
-      // WHO does it is a matter of balance only.  A workgroup has nbn tiles of 30-90 us and a tail costs ~20 us: if the last
-      // arriver always did the tail, the workgroups delayed by one tail would be the last arrivers of the next round too and a
-      // few of them would do three.  So: after a tile that is not its last a workgroup takes ONE job and only if it has not
-      // done one yet (its own image if it completed it, else a published one of its XCD's id range); a last arriver that may
-      // not take its image publishes it; after its last tile a workgroup takes jobs until nothing is published anywhere.
-      // Nobody waits for anybody, and a published image is always found: at the latest by the final sweep of the workgroup
-      // that published it.  The fast path (last arriver, eligible) is ONE atomic round trip; the first 64 words of the sweep
-      // are requested together with the ticket.
-      constexpr uint32_t LNT_FREE = 0x100u;
+    if constexpr (LNX) {
+      // ---- the LayerNorm of this tile's 256 x 256 block of the new residual stream (GemmArgs::ln_*; canonical arithmetic: see
+      // ln_lane_stats).  Barriers below are the plain kind: both wave rows are in step again.
+      typedef __attribute__((address_space(3))) float lds_f;
+      typedef __attribute__((address_space(3))) f32x4 lds_f4;
+      typedef __attribute__((address_space(3))) uint32_t lds_u;
+      lds_f* stat = (lds_f*)((lds_char*)smem + LNX_STAT);
+      lds_f* mr = (lds_f*)((lds_char*)smem + LNX_MR);
+      volatile lds_u* ctrl = (volatile lds_u*)((lds_char*)smem + LNX_CTRL);
+      const int img = ctm, ct = cn0 / HBN_;
+      // the arguments are re-read from the kernarg segment behind an opaque pointer: none of them is kept in an SGPR across the K loops
+      typedef const __attribute__((address_space(4))) GemmArgs* karg_ptr;
+      karg_ptr gp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(gp));
+      // an opaque copy of the thread id: nothing this block derives from it can be computed in front of the K loop and kept in
+      // registers across it (the K loop has none to spare)
+      int tid_x = tid;
+      asm volatile("" : "+v"(tid_x));
+      const int lane_x = tid_x & 63, fr_x = lane_x & 15, fq_x = lane_x >> 4;
+      const uint32_t row0 = (uint32_t)(img * gp->S + 1 + wm * 128 + 4 * fq_x);        // global row of this lane_x's (mt, r) = (0, 0)
+      const float invE = 1.f / (float)gp->N;
 #ifdef HVLA_BENCH_HOOKS
       const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+      unsigned long long dbg_wait = 0;
 #endif
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      volatile int* lctrl = reinterpret_cast<volatile int*>(smem + LNT_CTRL);
-      const bool final_tile = !more;
-      // the images that have a tile in the id range of this workgroup's XCD label (blockIdx % 8; tile_origin: with GN == nbn
-      // -- true for N <= 1024 -- an image's tiles are nbn consecutive ids).  Computed here, not kept across the K loops.
-      int img_lo, img_hi;
-      {
-        const int q = ntiles / 8, r = ntiles % 8, xcd = (int)blockIdx.x % 8;
-        const int b0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
-        img_lo = b0 / nbn;
-        img_hi = cnt > 0 ? (b0 + cnt - 1) / nbn + 1 : img_lo;
+#define HVLA_LBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+      // [A] x = residual + (acc + bias row) * layer scale (PATCH: position embedding + acc + bias) -> back into the accumulators
+      // x and h are addressed as buffers: ONE per-lane_x offset (the lane_x's row (mt, r) = (0, 0), its four columns) plus a scalar
+      // row offset per access -- no per-row address registers beside the 128 of xk
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(gp->out, 0, (int)gp->out_bytes, 0x00020000);
+      const uint32_t lane_e = row0 * (uint32_t)gp->N + (uint32_t)(wn * 64 + 4 * fr_x);     // element offset of (row0, this lane_x's columns of a tile at column 0)
+      f32x4 xk[8][4];                                    // [mt][r]: x of row 16 mt + 4 fq + r of the wave's 128, columns 4 fr .. 4 fr + 3 of its 64
+      {                                                  // (every wave: one whose 64 columns do not exist computes on zeros / whatever the
+                                                         // next row holds, counts as zeros below and stores nothing -- a branch here would
+                                                         // make xk a phi of 128 zeros that are live beside the accumulators)
+        // gemm_epilogue_rows_impl's arithmetic (RES: fma(acc + bias row, layer scale, x); PATCH: position + fma(acc, 1/256, bias)),
+        // one m-tile (four rows) at a time, two m-tiles requested ahead: 8-12 loads in flight.  The accumulators of an m-tile die
+        // where its four rows of xk are born (the K loop runs at the register limit: there is no room for both arrays).
+        __amdgpu_buffer_rsrc_t irs = xrs;
+        uint32_t ivo = (lane_e + (uint32_t)cn0) * 4u;
+        if constexpr (EPI == EPI_PATCH) {
+          irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp->aux), 0, gp->S * gp->N * 4, 0x00020000);
+          ivo = ((uint32_t)(1 + wm * 128 + 4 * fq_x) * (uint32_t)gp->N + (uint32_t)(cn0 + wn * 64 + 4 * fr_x)) * 4u;
+        }
+        const float q = gp->qscale;
+        f32x4 xin[3][4];                                 // a ring of three m-tiles
+        int rowb = gp->N * 4;                              // bytes per row; opaque at every site that forms the 32 scalar row offsets: shared, the
+        asm volatile("" : "+s"(rowb));                   // compiler keeps all of them in SGPRs through the epilogue and spills a hundred others
+        auto request = [&](int mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            xin[mt % 3][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)ivo, (16 * mt + r) * rowb, (EPI == EPI_RES && NTOUT) ? 2 : 0));   // aux 2 = nt
+        };
+        request(0);
+        request(1);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          if (mt + 2 < 8) request(mt + 2);
+          f32x4 t[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if constexpr (EPI == EPI_PATCH) t[c] = __builtin_elementwise_fma(acc[c][mt], f32x4{q, q, q, q}, f32x4{pb4[c], pb4[c], pb4[c], pb4[c]});
+            else t[c] = acc[c][mt] + pb4[c];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            f32x4 x = xin[mt % 3][r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if constexpr (EPI == EPI_RES) x[c] = fmaf(t[c][r], pl4[c], x[c]);
+              else x[c] += t[c][r];
+            }
+            xk[mt][r] = x;
+            asm volatile("" : "+v"(xk[mt][r]));          // computed HERE (left alone, the arithmetic is sunk to its first use, far below,
+          }                                              // and the 32 loads' destinations all stay live: spills)
+          __builtin_amdgcn_sched_barrier(0);             // (m-tile mt + 3 is not requested before this one is done: registers)
+        }
       }
-      const uint32_t w_free = (uint32_t)nbn | LNT_FREE;
-      auto claim = [&](int img) -> bool {               // wave 0; lane 0's compare-and-swap published -> owned, broadcast
-        uint32_t ok = 0;
-        if (lane == 0) {
-          uint32_t expect = w_free;
-          ok = __hip_atomic_compare_exchange_strong(g.ln_cnt + img, &expect, (uint32_t)nbn, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+#ifdef HVLA_BENCH_HOOKS
+      const unsigned long long dbg_tA = __builtin_readcyclecounter();
+#endif
+      // [B] (sum, sum of squares) of every row over this wave's 64 columns -> LDS; the four waves of a wave row -> the tile's
+      // partial of the row -> ln_part (write-through); drain; one lane counts the tile in
+      const float vmask = wvalid ? 1.f : 0.f;
+#ifndef HVLA_T_NOSTATS
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        float sv[4], qv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ln_lane_stats(xk[mt][r], sv[r], qv[r]);
+          sv[r] = row16_sum(sv[r]) * vmask;              // (x 1.0f is exact; x 0.0f of a finite number: an absent wave counts as zeros)
+          qv[r] = row16_sum(qv[r]) * vmask;
         }
-        return __builtin_amdgcn_readfirstlane(ok) != 0;
-      };
-      auto peek = [&](int base, int hi) -> uint32_t {   // wave 0: lane l reads the word of image base + l
-        const int i = base + lane;
-        return i < hi ? __hip_atomic_load(g.ln_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      };
-      auto pick = [&](int base, uint32_t v) -> int {    // wave 0: claim one of the published images among 64 peeked words
-        unsigned long long m = __ballot(v == w_free);
-        while (m) {
-          const int img = base + __builtin_ctzll(m);
-          if (claim(img)) return img;
-          m &= m - 1;
+        if (fr_x == 0) {
+          lds_f4* d = (lds_f4*)(stat + (wn * 256 + wm * 128 + 16 * mt + 4 * fq_x) * 2);
+          d[0] = f32x4{sv[0], qv[0], sv[1], qv[1]};
+          d[1] = f32x4{sv[2], qv[2], sv[3], qv[3]};
         }
-        return -1;
+        __builtin_amdgcn_sched_barrier(0);               // one m-tile's eight reductions at a time (register pressure)
+      }
+#endif
+      HVLA_LBAR();
+      if (tid_x < 256) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) f2 lds_f2;
+        const f2 p0 = *(lds_f2*)(stat + (0 * 256 + tid_x) * 2), p1 = *(lds_f2*)(stat + (1 * 256 + tid_x) * 2);
+        const f2 p2 = *(lds_f2*)(stat + (2 * 256 + tid_x) * 2), p3 = *(lds_f2*)(stat + (3 * 256 + tid_x) * 2);
+        const f2 pt = (p0 + p1) + (p2 + p3);
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(gp->ln_part, 0, (int)gp->part_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pt), prs, (int)((uint32_t)((img * nbn + ct) * 256 + tid_x) * 8u), 0, 16);   // aux 16 = sc1
+      }
+      // scale / bias of the LayerNorm for this lane_x's four columns: requested here (the residual rows' registers are free again),
+      // waited for with the partials
+      f32x4 lg4 = f32x4{0.f, 0.f, 0.f, 0.f}, lb4 = lg4;
+      if (wvalid) {
+        const uint32_t vcol = (uint32_t)(cn0 + wn * 64 + 4 * fr_x);
+        lg4 = *reinterpret_cast<const f32x4*>(gp->ln_scale + vcol);
+        lb4 = *reinterpret_cast<const f32x4*>(gp->ln_bias + vcol);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials are at the memory side (and the next tile's prologue DMA has landed)
+      asm volatile("" : "+v"(lg4), "+v"(lb4));
+      HVLA_LBAR();
+      const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(gp->ln_out, 0, (int)(gp->out_bytes / 4u * (uint32_t)sizeof(T)), 0x00020000);
+      auto store_x = [&]() {                             // the new residual rows, write-through: an abandoned tile is read back by another workgroup
+        if (!wvalid) return;
+#ifdef HVLA_T_NOSTOREX
+        return;
+#endif
+        const uint32_t vo = (lane_e + (uint32_t)cn0) * 4u;
+        int rowb = gp->N * 4;
+        asm volatile("" : "+s"(rowb));
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xk[mt][r]), xrs, (int)vo, (16 * mt + r) * rowb, 16);   // aux 16 = sc1
       };
-      auto sweep = [&](int lo, int hi, int skip) -> int {   // wave 0: a published image in [lo, hi), claimed; -1 if none
-        for (int base = lo; base < hi; base += 64) {
-          if (base == skip) continue;                       // (already peeked)
-          const int j = pick(base, peek(base, hi));
-          if (j >= 0) return j;
-        }
-        return -1;
-      };
-      int tails_done = 0;
+#ifdef HVLA_BENCH_HOOKS
+      const unsigned long long dbg_tB = __builtin_readcyclecounter();
+#endif
+      // [C] wave 0 counts the tile in and finds out about the image's other column tiles; the other waves store x meanwhile, and
+      // wave 1 normalises this tile's 256 columns of the image's CLS row (x[img * S] was finished by an earlier launch)
+      enum { LNX_GO = 0, LNX_LAST = 1, LNX_ABANDON = 2 };
       if (wave == 0) {
-        tails_done = __builtin_amdgcn_readfirstlane(lctrl[1]);
-        const bool elig = tails_done == 0 || final_tile;
+#ifdef HVLA_BENCH_HOOKS
+        const unsigned long long dbg_t1 = __builtin_readcyclecounter();
+#endif
         uint32_t old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(g.ln_cnt + ctm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t v0 = 0;
-        if (elig) v0 = peek(img_lo, img_hi);                // requested before the ticket's answer is needed
-        const uint32_t arrived = (__builtin_amdgcn_readfirstlane(old) & 0xffu) + 1u;
-        int job = -1;
-        if (arrived == (uint32_t)nbn) {
-          if (elig) job = ctm;                              // the image is this workgroup's
-          else if (lane == 0) __hip_atomic_fetch_or(g.ln_cnt + ctm, LNT_FREE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane_x == 0) old = __hip_atomic_fetch_add(gp->ln_cnt + img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        uint32_t status = LNX_ABANDON, abn = 0;
+        if ((old & 0xffffu) + 1u >= gp->ln_target) {
+          status = LNX_LAST;
+          abn = old >> 16;
+        } else if (!clater) {
+          const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+          while (true) {
+            uint32_t v = 0;
+            if (lane_x == 0) v = __hip_atomic_load(gp->ln_cnt + img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __builtin_amdgcn_readfirstlane(v);
+            if ((v & 0xffffu) >= gp->ln_target) { status = LNX_GO; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)gp->ln_spin) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
         }
-        if (job < 0 && elig) {
-          job = pick(img_lo, v0);
-          if (job < 0) job = sweep(img_lo, img_hi, img_lo);
-          if (job < 0 && final_tile) job = sweep(0, nbm, -1);
-        }
-        if (job >= 0) {
+        if (status != LNX_ABANDON) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (lane == 0) *lctrl = job;
-      }
-      __syncthreads();
-      int job = *lctrl;
-      __syncthreads();                                    // (the word is read by every wave before wave 0 writes it again)
+        if (lane_x == 0) ctrl[0] = status, ctrl[1] = abn;
 #ifdef HVLA_BENCH_HOOKS
-      const unsigned long long dbg_t1 = __builtin_readcyclecounter();
-      if (tid == 0 && blockIdx.x < 256) {
-        atomicAdd(&g_lnt_dbg[2][blockIdx.x], dbg_t1 - dbg_t0);
-        if (final_tile) atomicAdd(&g_lnt_dbg[3][blockIdx.x], 1ull);
-      }
+        dbg_wait = __builtin_readcyclecounter() - dbg_t1;
 #endif
-      while (job >= 0) {
-        {
-          const float* jx = reinterpret_cast<const float*>(g.out) + (size_t)job * g.S * g.N;
-          T* jout = reinterpret_cast<T*>(g.ln_out) + (size_t)job * g.S * g.N;
-          T* jabar = g.ln_abar ? reinterpret_cast<T*>(g.ln_abar) + (size_t)job * 2 * g.N : nullptr;
-          lds_char* jlds = (lds_char*)smem + LNT_SCRATCH;
-          // an opaque copy of the thread id: nothing the tail derives from it can be hoisted out of the tile loop (lane-constant
-          // addresses computed at kernel entry stay live through the K loops, which have no register to spare)
-          int tid_t = tid;
-          asm volatile("" : "+v"(tid_t));
-          if (g.N == 768) ln_tail<Op, 3, true>(jx, jout, g.ln_scale, g.ln_bias, jabar, g.S, g.N, g.hsplit, jlds, wave, tid_t);
-          else if (g.N == 1024) ln_tail<Op, 4, true>(jx, jout, g.ln_scale, g.ln_bias, jabar, g.S, g.N, g.hsplit, jlds, wave, tid_t);
-          else ln_tail<Op, 4, false>(jx, jout, g.ln_scale, g.ln_bias, jabar, g.S, g.N, g.hsplit, jlds, wave, tid_t);
-        }
-        ++tails_done;
-        __syncthreads();                                  // the scratch is free again (next job / next tile's W halves)
-#ifdef HVLA_BENCH_HOOKS
-        if (tid == 0 && blockIdx.x < 256) atomicAdd(&g_lnt_dbg[0][blockIdx.x], 1ull);
-#endif
-        if (wave == 0) {
-          if (lane == 0) __hip_atomic_store(g.ln_cnt + job, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-          int nj = -1;
-          if (final_tile) {
-            nj = sweep(img_lo, img_hi, -1);
-            if (nj < 0) nj = sweep(0, nbm, -1);
-            if (nj >= 0) {
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+      } else {
+        store_x();
+#ifndef HVLA_T_NOCLS
+        if (wave == 1) {
+          const int n4 = gp->N / 4;
+          const f32x4* xr = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(gp->out) + (size_t)img * gp->S * gp->N);
+          f32x4 cur[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cur[i] = lane_x + 64 * i < n4 ? xr[lane_x + 64 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
+          float mean, rstd;
+          ln_row_stats<4>(cur, invE, mean, rstd);
+          const f32x4 mine = ct == 0 ? cur[0] : (ct == 1 ? cur[1] : (ct == 2 ? cur[2] : cur[3]));
+          const int col = lane_x + 64 * ct;
+          if (col < n4) {
+            const f32x4 s4 = reinterpret_cast<const f32x4*>(gp->ln_scale)[col], b4 = reinterpret_cast<const f32x4*>(gp->ln_bias)[col];
+            typename Op::x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (T)ln_value(mine[j], mean, rstd, s4[j], b4[j]);
+            reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_out) + (size_t)img * gp->S * gp->N)[col] = o;
           }
-          if (lane == 0) *lctrl = nj, lctrl[1] = tails_done;
         }
-        __syncthreads();
-        job = *lctrl;
-        __syncthreads();
+#endif
+      }
+      HVLA_LBAR();
+      uint32_t status = ctrl[0], abn = ctrl[1];
+      if (wave == 0) store_x();
+      if (status == LNX_ABANDON) {
+        // not waiting: x of this tile to the memory side, then the mark -- unless everybody has arrived meanwhile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HVLA_LBAR();                                     // (also: every wave has read ctrl)
+        if (wave == 0) {
+          uint32_t old = 0;
+          if (lane_x == 0) old = __hip_atomic_fetch_or(gp->ln_cnt + img, 0x10000u << ct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          old = __builtin_amdgcn_readfirstlane(old);
+          uint32_t st2 = LNX_ABANDON;
+          if ((old & 0xffffu) >= gp->ln_target) {          // the last arriver did not see the mark: take it back, normalise here
+            if (lane_x == 0) __hip_atomic_fetch_and(gp->ln_cnt + img, ~(0x10000u << ct), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st2 = LNX_GO;
+          }
+          if (lane_x == 0) ctrl[0] = st2;
+        }
+        HVLA_LBAR();
+        status = ctrl[0];
       }
 #ifdef HVLA_BENCH_HOOKS
-      if (tid == 0 && blockIdx.x < 256) atomicAdd(&g_lnt_dbg[1][blockIdx.x], (unsigned long long)__builtin_readcyclecounter() - dbg_t1);
+      unsigned long long dbg_slow = 0;
+      const unsigned long long dbg_tC = __builtin_readcyclecounter();
 #endif
+      if (status != LNX_ABANDON) {
+        // [D] the image's partials in column-tile order -> (mean, rstd) of this tile's 256 rows
+        if (tid_x < 256) {
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          f2 pp[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < nbn) pp[c] = *reinterpret_cast<const f2*>(gp->ln_part + (size_t)((img * nbn + c) * 256 + tid_x) * 2);
+          f2 t = pp[0];
+#pragma unroll
+          for (int c = 1; c < 4; ++c)
+            if (c < nbn) t += pp[c];
+          float mean, rstd;
+          ln_finish(t[0], t[1], invE, mean, rstd);
+          *(__attribute__((address_space(3))) f2*)(mr + tid_x * 2) = f2{mean, rstd};
+        }
+        HVLA_LBAR();
+        // [E] normalise from the registers: h (16-bit) and this wave's 64 columns of the wave row's mean row
+        auto sweep = [&](int ctile, f32x4 gm4, f32x4 bt4) {
+          const uint32_t ncol = (uint32_t)(ctile * HBN_ + wn * 64 + 4 * fr_x);
+          const uint32_t vo = (lane_e + (uint32_t)(ctile * HBN_)) * (uint32_t)sizeof(T);
+          int rowb = gp->N * (int)sizeof(T);
+          asm volatile("" : "+s"(rowb));
+          f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) {
+            const lds_f4* mp = (const lds_f4*)(mr + (wm * 128 + 16 * mt + 4 * fq_x) * 2);
+            const f32x4 m01 = mp[0], m23 = mp[1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float mean = r < 2 ? m01[2 * r] : m23[2 * r - 4], rstd = r < 2 ? m01[2 * r + 1] : m23[2 * r - 3];
+              typename Op::x4 o;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float y = ln_value(xk[mt][r][c], mean, rstd, gm4[c], bt4[c]);
+                cs[c] = (mt == 0 && r == 0) ? y : cs[c] + y;                     // ascending rows
+                o[c] = (T)y;
+              }
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), hrs, (int)vo, (16 * mt + r) * rowb, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (gp->ln_abar) {
+            typename Op::x4 mo;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              float t = cs[c];
+              t += __shfl_xor(t, 16, 64);
+              t += __shfl_xor(t, 32, 64);                                        // (p0 + p1) + (p2 + p3)
+              mo[c] = (T)(t * (1.f / 128.f));
+            }
+            if (fq_x == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_abar) + ((size_t)img * 2 + wm) * gp->N + ncol) = mo;
+          }
+        };
+#ifndef HVLA_T_NOSWEEP
+        if (wvalid) sweep(ct, lg4, lb4);
+#endif
+        // [F] the image's last arriver: the tiles that did not wait, from the x they stored
+#ifndef HVLA_T_NOSLOW
+        if (status == LNX_LAST && abn) {
+#ifdef HVLA_BENCH_HOOKS
+          dbg_slow = __builtin_popcount(abn);
+#endif
+          for (int c = 0; c < nbn; ++c) {
+            if (!((abn >> c) & 1u) || c * HBN_ + wn * 64 >= gp->N) continue;       // (wave-uniform)
+            const uint32_t ncol = (uint32_t)(c * HBN_ + wn * 64 + 4 * fr_x);
+            const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gp->ln_scale + ncol), bt4 = *reinterpret_cast<const f32x4*>(gp->ln_bias + ncol);
+            const uint32_t vo = (lane_e + (uint32_t)(c * HBN_)) * 4u;
+            int rowb = gp->N * 4;
+            asm volatile("" : "+s"(rowb));
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                xk[mt][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)vo, (16 * mt + r) * rowb, 0));
+            sweep(c, gm4, bt4);
+          }
+          if (tid_x == 0) __hip_atomic_fetch_and(gp->ln_cnt + img, 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the marks, for the next launch
+        }
+#endif
+      }
+#ifdef HVLA_BENCH_HOOKS
+      if (tid_x == 0 && blockIdx.x < 256) {
+        atomicAdd(&g_lnx_dbg[0][blockIdx.x], 1ull);
+        atomicAdd(&g_lnx_dbg[1][blockIdx.x], (unsigned long long)__builtin_readcyclecounter() - dbg_t0);
+        atomicAdd(&g_lnx_dbg[2][blockIdx.x], dbg_wait);
+        if (status == LNX_ABANDON) atomicAdd(&g_lnx_dbg[3][blockIdx.x], 1ull);
+        if (dbg_slow) atomicAdd(&g_lnx_dbg[4][blockIdx.x], dbg_slow);
+        atomicAdd(&g_lnx_dbg[5][blockIdx.x], dbg_tA - dbg_t0);
+        atomicAdd(&g_lnx_dbg[6][blockIdx.x], dbg_tB - dbg_tA);
+        atomicAdd(&g_lnx_dbg[7][blockIdx.x], (unsigned long long)__builtin_readcyclecounter() - dbg_tC);
+      }
+#endif
+#undef HVLA_LBAR
       if (!more) break;
-      continue;                                           // (the vmcnt(0) above covers the wait below)
+      continue;                                          // (K-tile 0 of the next tile landed in front of the count-in: vmcnt(0) above)
     }
     if (!more) break;
     // K-tile 0 of the next tile must have landed: its PRO_DMA_KT0 instructions are the oldest of the PRO_DMA + (epilogue)
@@ -1472,142 +1646,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       }
     }
   }
-}
-
-// LayerNorm in front of a GEMM (norm1 / norm2), with the mean row of its output that the GEMM's weight-rounding
-// compensation needs (the corr rows of gemm64_kernel).  ONE workgroup of 16 waves per image: wave w normalises rows
-// w, w + 16, w + 32, ... one after the other (the next row's loads in flight under this row's arithmetic), each lane keeps
-// the running f32 sums of its columns, and the 16 waves are combined through LDS in wave order -- the mean row abar[b] comes
-// out of the same launch (no partial sums in memory, no second kernel), and the order of the additions depends on nothing
-// but the image.  A batch of 256 images is exactly one workgroup per CU.  E % 4 == 0, E <= 1024.
-template <typename Op>
-__global__ __launch_bounds__(LNW * 64) void layernorm_img_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
-                                                                 const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                 typename Op::elem* __restrict__ abar, int S, int E, int hsplit) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [2 halves][LNW][E / 4]
-  const int b = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n4 = E / 4;
-  f32x4 cs[4], cs1[4], cur[4], nxt[4], s4[4], b4[4];                 // cs: rows [0, hsplit), cs1: rows [hsplit, S)
-  auto load = [&](f32x4 (&v)[4], int row) {
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((size_t)b * S + (row < S ? row : S - 1)) * E);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = lane + 64 * i;
-      // non-temporal: x is not read again before the next residual epilogue, a whole GEMM later; kept out of the way, the
-      // 16-bit rows this kernel writes stay closer to the GEMM that reads them next (QKV 2.52 -> 2.47 ms per step)
-      v[i] = col < n4 ? __builtin_nontemporal_load(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int col = lane + 64 * i;
-    cs[i] = cs1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s4[i] = col < n4 ? reinterpret_cast<const f32x4*>(scale)[col] : cs[i];
-    b4[i] = col < n4 ? reinterpret_cast<const f32x4*>(bias)[col] : cs[i];
-  }
-  // scale / bias are waited for HERE: left to the compiler, the wait for them is a vmcnt(0) at their first use inside the row
-  // loop, executed every iteration, which also waits for the next row's loads just issued (the prefetch was dead: 62 against
-  // 54 us per launch)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(s4[i]), "+v"(b4[i]));
-  load(cur, wave);
-  for (int row = wave; row < S; row += LNW) {                        // wave-uniform
-    load(nxt, row + LNW);
-    f32x4 y[4];
-    ln_row<Op>(cur, s4, b4, n4, 1.f / (float)E, lane, out + ((size_t)b * S + row) * E, y);
-    if (row < hsplit) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cs[i] += y[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cs1[i] += y[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-  }
-  if (!abar) return;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (lane + 64 * i < n4) red[wave * n4 + lane + 64 * i] = cs[i], red[(LNW + wave) * n4 + lane + 64 * i] = cs1[i];
-  __syncthreads();
-  if ((int)threadIdx.x < 2 * n4) {                                   // threads [0, n4): half 0, [n4, 2 n4): half 1
-    const int hf = (int)threadIdx.x >= n4, c4 = threadIdx.x - hf * n4;
-    f32x4 t = red[hf * LNW * n4 + c4];
-#pragma unroll
-    for (int w = 1; w < LNW; ++w) t += red[(hf * LNW + w) * n4 + c4];
-    const float inv = 1.f / (float)(hf ? S - hsplit : hsplit);
-    typename Op::x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (typename Op::elem)(t[j] * inv);
-    reinterpret_cast<typename Op::x4*>(abar + ((size_t)b * 2 + hf) * E)[c4] = o;
-  }
-}
-
-// The same LayerNorm for SMALL batches, where one workgroup per image leaves the chip empty and a launch lasts as long as one
-// CU needs for 257 rows (26 us at B = 1, 25 launches per step): LNW workgroups per image, workgroup j takes the rows of
-// "wave j" of the kernel above (j, j + 16, ...), one row per wave, and adds their y in that same order (through LDS) into
-// partial[b][j][E]; layernorm_mean_kernel then combines the LNW partials in wave order.  Same additions in the same order =>
-// the same mean row, bit for bit, whichever form ran (the batch-invariance tests cross them).
-template <typename Op>
-__global__ __launch_bounds__(LNW * 64) void layernorm_split_kernel(const float* __restrict__ x, typename Op::elem* __restrict__ out,
-                                                                   const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                   float* __restrict__ partial, int S, int E, int hsplit) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* ys = reinterpret_cast<f32x4*>(smem);                        // [rows of this workgroup][E / 4]
-  const int j = blockIdx.x, b = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n4 = E / 4;
-  const int nrows = (S - j + LNW - 1) / LNW;                         // rows j, j + LNW, ...: 16 or 17 at S = 257
-  f32x4 s4[4], b4[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int col = lane + 64 * i;
-    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-    s4[i] = col < n4 ? reinterpret_cast<const f32x4*>(scale)[col] : z;
-    b4[i] = col < n4 ? reinterpret_cast<const f32x4*>(bias)[col] : z;
-  }
-  for (int v = wave; v < nrows; v += LNW) {                          // wave-uniform; one row per wave, a second one for row 256
-    const int row = j + LNW * v;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((size_t)b * S + row) * E);
-    f32x4 cur[4], y[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = lane + 64 * i;
-      cur[i] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    ln_row<Op>(cur, s4, b4, n4, 1.f / (float)E, lane, out + ((size_t)b * S + row) * E, y);
-    if (partial) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (lane + 64 * i < n4) ys[v * n4 + lane + 64 * i] = y[i];
-    }
-  }
-  if (!partial) return;
-  __syncthreads();
-  if ((int)threadIdx.x < 2 * n4) {                                   // partial[b][half][j][E]: the rows of "wave j" that lie in that half
-    const int hf = (int)threadIdx.x >= n4, c4 = threadIdx.x - hf * n4;
-    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int v = 0; v < nrows; ++v)
-      if ((j + LNW * v >= hsplit) == (hf != 0)) cs += ys[v * n4 + c4];
-    reinterpret_cast<f32x4*>(partial + (((size_t)b * 2 + hf) * LNW + j) * E)[c4] = cs;
-  }
-}
-template <typename Op>
-__global__ __launch_bounds__(256) void layernorm_mean_kernel(const float* __restrict__ partial, typename Op::elem* __restrict__ abar,
-                                                             int S, int E, int hsplit) {
-  const int bh = blockIdx.x, n4 = E / 4;                             // (image, half)
-  if ((int)threadIdx.x >= n4) return;
-  const f32x4* p = reinterpret_cast<const f32x4*>(partial + (size_t)bh * LNW * E);
-  f32x4 t = p[threadIdx.x];
-#pragma unroll
-  for (int w = 1; w < LNW; ++w) t += p[w * n4 + threadIdx.x];
-  const float inv = 1.f / (float)((bh & 1) ? S - hsplit : hsplit);
-  typename Op::x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (typename Op::elem)(t[j] * inv);
-  reinterpret_cast<typename Op::x4*>(abar + (size_t)bh * E)[threadIdx.x] = o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2018,11 +2056,12 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     SETA((gemm256p_kernel<Op, EPI_GELU, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true>))
     SETA((gemm256p_kernel<Op, EPI_PATCH, false, true>)) SETA((gemm256p_kernel<Op, EPI_RES, false, true>))
     SETA((gemm256p_kernel<Op, EPI_PATCH, true, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true, true>))
+    SETA((gemm256p_kernel<Op, EPI_RES, false, true, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true, true, true>))
     SETA((gemm64_kernel<Op, EPI_PATCH>)) SETA((gemm64_kernel<Op, EPI_QKV>)) SETA((gemm64_kernel<Op, EPI_GELU>))
     SETA((gemm64_kernel<Op, EPI_RES>)) SETA((gemm64_kernel<Op, EPI_CORR>))
     SETA((gemm64_kernel<Op, EPI_QKV, 4>)) SETA((gemm64_kernel<Op, EPI_GELU, 4>)) SETA((gemm64_kernel<Op, EPI_RES, 4>))
     SETA((gemm64c_kernel<Op, EPI_QKV>)) SETA((gemm64c_kernel<Op, EPI_GELU>)) SETA((gemm64c_kernel<Op, EPI_RES>)) SETA((gemm64c32_kernel<Op>))
-    SETA((gemm64c_kernel<Op, EPI_QKV, true>)) SETA((gemm64c_kernel<Op, EPI_GELU, true>))
+    SETA((gemm64c_kernel<Op, EPI_QKV, true>)) SETA((gemm64c_kernel<Op, EPI_GELU, true>)) SETA((layernorm_group_kernel<Op>))
     SETA((gemm256p_kernel<Op, EPI_QKV, false, false, true>)) SETA((gemm256p_kernel<Op, EPI_GELU, false, false, true>))
     SETA((gemm256p_kernel<Op, EPI_QKV, true, false, true>)) SETA((gemm256p_kernel<Op, EPI_GELU, true, false, true>))
     SETA((gemm256p_kernel<Op, EPI_RES, false, false, true>)) SETA((gemm256p_kernel<Op, EPI_RES, true, false, true>))
@@ -2044,16 +2083,40 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   //  * otherwise a corr-only gemm64_kernel launch, then gemm64_kernel (<= 2047 rows) or gemm_kernel (128x128 tiles) over all rows, bias row
   //    looked up per row.
   // Returns whether the image-aligned form ran (then a GELU epilogue writes the mean row of its output itself).
-  // ln_s / ln_b (RES only): scale and bias of the LayerNorm that follows this GEMM; the image-aligned form runs it as its tail
-  // (GemmArgs::ln_*) and sets ln_fused, otherwise the caller launches it.
+  // ln_s / ln_b (RES only): scale and bias of the LayerNorm that follows this GEMM; the image-aligned form runs it inside its
+  // epilogue (GemmArgs::ln_*, gemm256p_kernel<..., LNX>) and sets ln_fused, otherwise the caller launches it.
   bool ln_fused = false;
+  uint32_t ln_launch = 0;              // LNX launches of this call so far: the count an image's word reaches is launch number x nbn
   // small batch: does the GEMM [M][K] x [N][K] run as gemm64c_kernel (bias rows computed inside)?  ...and may it also add up the
   // mean rows from the LayerNorm's partials (FOLD)?  ln_partial: set by layernorm() when it left the mean rows to its consumer.
   auto small_fused = [&](int N, int K) {
     return comp && M <= G64_MAXM && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31) && N % SBN == 0 && K % 64 == 0 && S >= 9;
   };
   const float* ln_partial = nullptr;
-  const bool can_fuse_ln = ws.ln_cnt != nullptr && (size_t)M * E * 4 < (1ull << 32) && E <= 1024;
+#ifdef HVLA_EXP_NOLNX
+  const bool can_fuse_ln = false;
+#else
+  const bool can_fuse_ln = ws.ln_cnt != nullptr && ws.ln_part != nullptr && (size_t)M * E * 4 < (1ull << 32) && E <= 1024;
+#endif
+  // the persistent form of an LNX launch keeps the nbn column tiles of an image in one round (tile_origin_x): the counts must divide
+  auto lnx_persistent = [&](int nbm_, int nbn_) {
+    const int nt = nbm_ * nbn_;
+    if (ncu % 8 || nt % ncu || nbm_ % 8) return false;
+    const int Wx = ncu / 8, odd = Wx % nbn_, R = nt / ncu;
+    return Wx >= nbn_ && (odd == 0 || R % nbn_ == 0);
+  };
+  auto lnx_args = [&](GemmArgs& a, const float* ln_s, const float* ln_b, int nbn_) {
+    a.ln_out = ws.h; a.ln_scale = ln_s; a.ln_bias = ln_b; a.ln_abar = comp ? ws.abar : nullptr; a.ln_cnt = ws.ln_cnt; a.ln_part = ws.ln_part;
+    a.out_bytes = (uint32_t)((size_t)M * E * 4);
+    a.part_bytes = (uint32_t)((size_t)B * nbn_ * 256 * 2 * sizeof(float));
+    a.ln_target = ++ln_launch * (uint32_t)nbn_;
+    a.ln_spin = ws.ln_spin;
+    if (lnx_persistent((int)a.nbm, nbn_)) {
+      const int Wx = ncu / 8, R = a.nbm * nbn_ / ncu;
+      a.lnx_G = Wx / nbn_; a.lnx_rows_aligned = R * a.lnx_G; a.lnx_rounds_div = R / nbn_; a.lnx_rows_xcd = a.nbm / 8;
+      a.lnx_rcp = (65536 + nbn_ - 1) / nbn_;
+    }
+  };
   auto gemm = [&](auto epic, const void* A, const void* Wt, const void* dW, int N, int K, const float* bias, const float* aux,
                   void* out, int qcols, int cat, void* colmean = nullptr, const float* ln_s = nullptr, const float* ln_b = nullptr) -> bool {
     constexpr int EPI = decltype(epic)::value;
@@ -2087,11 +2150,16 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       const size_t lds = 131072;
       pf.begin(cat, st);
       if constexpr (EPI == EPI_RES) {
-        if (ln_s && can_fuse_ln) {                     // the LayerNorm behind this GEMM as its tail
-          a.ln_out = ws.h; a.ln_scale = ln_s; a.ln_bias = ln_b; a.ln_abar = comp ? ws.abar : nullptr; a.ln_cnt = ws.ln_cnt;
-          a.out_bytes = (uint32_t)((size_t)M * N * 4);
-          if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true, true>), dim3(ncu), dim3(512), LNT_LDS, st, a);
-          else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false, true>), dim3(B * nbn), dim3(512), LNT_LDS, st, a);
+        if (ln_s && can_fuse_ln) {                     // the LayerNorm behind this GEMM inside its epilogue
+          lnx_args(a, ln_s, ln_b, nbn);
+          const bool nt = (size_t)M * N * sizeof(float) >= ((size_t)96 << 20);      // a big batch: the residual rows are read past L2 (below)
+          if (lnx_persistent(B, nbn)) {
+            if (nt) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true, true, true>), dim3(ncu), dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true, true>), dim3(ncu), dim3(512), lds, st, a);
+          } else {
+            if (nt) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false, true, true>), dim3(B * nbn), dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false, true>), dim3(B * nbn), dim3(512), lds, st, a);
+          }
           pf.end(cat, st);
           ln_fused = true;
           return true;
@@ -2155,31 +2223,26 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     pf.end(cat, st);
     return false;
   };
-  constexpr int LN_SPLIT_MAXB = 64;    // up to here a LayerNorm is LNW workgroups per image + a finalising launch (same bits)
   // Nnext: width of the GEMM that reads the output.  scratch / scratch_cols: a 16-bit [M][scratch_cols] workspace buffer that is free
   // from this launch until its consumer GEMM has ENDED (norm1: ws.g, QKV writes ws.qkv; norm2: ws.qkv, fc1 writes ws.g), for the
-  // partial column sums [B][2][LNW][E] f32
+  // partial column sums [B][LNG][E] f32
   auto layernorm = [&](const float* sc, const float* bi, int Nnext, void* scratch, int scratch_cols) {   // norm1 / norm2 (+ the column sums of the output)
-    if (B <= LN_SPLIT_MAXB && E <= 1024 && (size_t)2 * LNW * E * sizeof(float) <= (size_t)S * scratch_cols * sizeof(T)) {
-      float* partial = comp ? reinterpret_cast<float*>(scratch) : nullptr;
-      hipLaunchKernelGGL((layernorm_split_kernel<Op>), dim3(LNW, B), dim3(LNW * 64), (size_t)((S + LNW - 1) / LNW) * E * sizeof(float),
-                         st, ws.x, reinterpret_cast<T*>(ws.h), sc, bi, partial, S, E, hsplit);
-      // (one launch with the image's last workgroup to arrive -- ticket by atomicAdd behind a __threadfence -- adding the
-      // partials was tried: 14.0 us against 5.2 + 4.7 for the two launches, profiles/r3_experiments_not_kept.txt)
+    const bool room = (size_t)LNG * E * sizeof(float) <= (size_t)S * scratch_cols * sizeof(T);
+    float* partial = comp && room ? reinterpret_cast<float*>(scratch) : nullptr;
+    hipLaunchKernelGGL((layernorm_group_kernel<Op>), dim3(LNG, B), dim3(LNW * 64), (size_t)(P / 8) * E * sizeof(float), st, ws.x,
+                       reinterpret_cast<T*>(ws.h), sc, bi, partial, S, P, E);
+    if (!partial) return;
+    // (one launch with the image's last workgroup to arrive -- ticket by atomicAdd behind a __threadfence -- adding the
+    // partials was tried: 14.0 us against 5.2 + 4.7 for the two launches, profiles/r3_experiments_not_kept.txt)
 #ifndef HVLA_EXP_NOFOLD
-      // B = 1: every workgroup of the consumer GEMM adds the partials up itself (gemm64c_kernel, FOLD) -- while that GEMM is ONE round
-      // of workgroups.  Same box, ms per step: B = 1 1.250 against 1.270 with the separate launch; B = 4 (612 workgroups, each re-adding
-      // 196 KB through its CU's memory pipe in front of its K loop) 1.93 against 1.85, so from two rounds on the launch stays.
-      if (comp && small_fused(Nnext, E) && gemm64c_fold_lds(E) <= 160 * 1024 && ((M + SBM - 1) / SBM) * (Nnext / SBN) <= ncu) {
-        ln_partial = partial;
-        return;
-      }
-#endif
-      if (comp) hipLaunchKernelGGL((layernorm_mean_kernel<Op>), dim3(2 * B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), S, E, hsplit);
+    // B = 1: every workgroup of the consumer GEMM adds the partials up itself (gemm64c_kernel, FOLD) -- while that GEMM is ONE round
+    // of workgroups (round 4, same box: B = 1 1.250 against 1.270 ms per step with the separate launch; B = 4 1.93 against 1.85).
+    if (small_fused(Nnext, E) && gemm64c_fold_lds(E) <= 160 * 1024 && ((M + SBM - 1) / SBM) * (Nnext / SBN) <= ncu) {
+      ln_partial = partial;
       return;
     }
-    hipLaunchKernelGGL((layernorm_img_kernel<Op>), dim3(B), dim3(LNW * 64), (size_t)2 * LNW * E * sizeof(float), st, ws.x,
-                       reinterpret_cast<T*>(ws.h), sc, bi, comp ? reinterpret_cast<T*>(ws.abar) : nullptr, S, E, hsplit);
+#endif
+    hipLaunchKernelGGL((layernorm_mean_kernel<Op>), dim3(2 * B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), P, E);
   };
   auto colmean_of = [&](const void* act, int K) {      // mean row of a GEMM output whose epilogue did not write it (no image-aligned tiles)
     if (!comp) return;
@@ -2190,8 +2253,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (!audit) return;
     hipLaunchKernelGGL((absmax_kernel<T>), dim3(1024), dim3(256), 0, st, reinterpret_cast<const T*>(buf), n / 8, audit + 2 * site);
   };
-  // tickets of the LayerNorm tails: zero before the first launch of every call (the last arriver of an image puts the zero
-  // back, so this only matters after a launch that did not finish; a memset node when the call is captured)
+  // the images' arrival words of the fused LayerNorms: zero before the first launch of every call (a memset node when the call is captured)
   if (can_fuse_ln && P == HBM_ && M > G64_MAXM && (e = hipMemsetAsync(ws.ln_cnt, 0, (size_t)((B * 4 + 15) / 16 * 16), st)) != hipSuccess) return e;
   using EQ = std::integral_constant<int, EPI_QKV>;
   using EG = std::integral_constant<int, EPI_GELU>;
@@ -2210,12 +2272,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (Mp % HBM_ == 0 && E % SBN == 0 && E >= HBN_ && Mp > G64_MAXM && fits32) {
       a.nbm = Mp / HBM_; a.tile_row0 = 0; a.tile_stride = HBM_;
       const int nbn = (E + HBN_ - 1) / HBN_;
-      if (P == HBM_ && can_fuse_ln && g.enc_layers > 0) {   // a tile row is an image: norm1 of layer 0 as the tail (the CLS rows are written above)
+      if (P == HBM_ && can_fuse_ln && g.enc_layers > 0) {   // a tile row is an image: norm1 of layer 0 inside the epilogue (the CLS rows are written above)
         a.hsplit = hsplit;
-        a.ln_out = ws.h; a.ln_scale = w.layer[0].ln1_s; a.ln_bias = w.layer[0].ln1_b; a.ln_abar = comp ? ws.abar : nullptr;
-        a.ln_cnt = ws.ln_cnt; a.out_bytes = (uint32_t)((size_t)M * E * 4);
-        if ((a.nbm * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true, true>), dim3(ncu), dim3(512), LNT_LDS, st, a);
-        else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false, true>), dim3(a.nbm * nbn), dim3(512), LNT_LDS, st, a);
+        lnx_args(a, w.layer[0].ln1_s, w.layer[0].ln1_b, nbn);
+        if (lnx_persistent(a.nbm, nbn)) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true, true>), dim3(ncu), dim3(512), 131072, st, a);
+        else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false, true>), dim3(a.nbm * nbn), dim3(512), 131072, st, a);
         ln_fused = true;
       } else if ((a.nbm * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true>), dim3(ncu), dim3(512), 131072, st, a);
       else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false>), dim3(a.nbm * nbn), dim3(512), 131072, st, a);
@@ -2273,12 +2334,12 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
 }
 
 #ifdef HVLA_BENCH_HOOKS
-hipError_t debug_lnt_stats(unsigned long long* out, int reset) {   // out: host [4][256]
+hipError_t debug_lnx_stats(unsigned long long* out, int reset) {   // out: host [8][256]
   hipError_t e = hipDeviceSynchronize();
-  if (e == hipSuccess && out) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lnt_dbg), sizeof(unsigned long long) * 4 * 256);
+  if (e == hipSuccess && out) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lnx_dbg), sizeof(unsigned long long) * 8 * 256);
   if (e == hipSuccess && reset) {
-    static unsigned long long zero[4][256];
-    e = hipMemcpyToSymbol(HIP_SYMBOL(g_lnt_dbg), zero, sizeof zero);
+    static unsigned long long zero[8][256];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_lnx_dbg), zero, sizeof zero);
   }
   return e;
 }

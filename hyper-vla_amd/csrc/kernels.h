@@ -62,7 +62,9 @@ struct EncWorkspace {
   float* corr;     // [B, 2, max(3E, F)] bias rows of the current GEMM per image half (bias + mean row of that half . dW)
   void* abar;      // [B, 2, max(E, F)] 16-bit mean rows (upper / lower half of the image) of the current GEMM's activation operand
   float* amap = nullptr;   // nullable: [B, enc_layers, enc_heads, P] attention of the CLS query over the patch keys (opt-in export)
-  uint32_t* ln_cnt = nullptr;   // nullable: [B rounded up to 4] tickets of the LayerNorm tails (encoder.hip GemmArgs::ln_cnt); null = LayerNorm as its own launch
+  uint32_t* ln_cnt = nullptr;   // nullable: [B rounded up to 4] arrival words of the LayerNorms fused into the residual GEMMs (encoder.hip GemmArgs::ln_cnt)
+  float* ln_part = nullptr;     // nullable: [B][4][256][2] per-row (sum, sum of squares) of every column tile (GemmArgs::ln_part); either null = LayerNorm as its own launch
+  uint32_t ln_spin = 800;       // how long a column tile waits for the image's other tiles before it leaves its share to the last arriver: ticks of 10 ns
 };
 // optional live timing: a pool of hipEvent pairs tagged with a category (include/hvla.h HVLA_PROF_*)
 struct Profiler {
@@ -95,7 +97,7 @@ hipError_t launch_encoder(const Geom& g, int dtype, const EncWeights& w, const E
 #ifdef HVLA_BENCH_HOOKS
 hipError_t debug_gemm(const void* A, const void* W, const float* bias, const float* aux, void* out, int M, int N,
                       int K, int epi, int variant, int iters, float* ms, hipStream_t st);
-hipError_t debug_lnt_stats(unsigned long long* out, int reset);   // [4][256]: LayerNorm tail jobs per workgroup id (encoder.hip g_lnt_dbg)
+hipError_t debug_lnx_stats(unsigned long long* out, int reset);   // [8][256]: fused-LayerNorm counters per workgroup id (encoder.hip g_lnx_dbg)
 hipError_t debug_ctx_stamps(unsigned long long* out);   // [64] shader-clock stamps of the last context-encoder launch
 hipError_t debug_attention_stamps(const void* qkv, void* o, void* omean, int B, int S, int E, int H, int wg, unsigned long long* stamps,
                                   hipStream_t st);
