@@ -164,7 +164,7 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   A(ctx->ws_corr, 2 * Bm * (F > 3 * E ? F : 3 * E) * 4);      // two rows per image (upper / lower half): encoder.hip GemmArgs::corr
   A(ctx->ws_abar, 2 * Bm * (F > E ? F : E) * 2);
   A(ctx->ws_lncnt, (Bm + 4) * 4 + 64);                          // arrival words of the fused LayerNorms, one per image (16-byte multiples per half batch)
-  A(ctx->ws_lnpart, Bm * 4 * 256 * 2 * 4);                      // their per-row partial statistics: [image][column tile <= 4][256][2] f32
+  A(ctx->ws_lnpart, Bm * 4 * 256 * 16);                         // their per-row partial statistics: [image][column tile <= 4][256] entries of 16 bytes
   if (e != hipSuccess) return HVLA_E_ARENA_FULL;
   if (hipMemset(ctx->ws_lncnt.p, 0, ctx->ws_lncnt.bytes) != hipSuccess) return HVLA_E_HIP;
   if (c->streams == 2) {
@@ -504,7 +504,7 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
                   static_cast<char*>(ctx->ws_abar.p) + (size_t)2 * b0 * (F > E ? F : E) * 2};
   if (ctx->amap_dino) ws.amap = ctx->amap_dino + (size_t)b0 * g.enc_layers * g.enc_heads * g.P();
   ws.ln_cnt = ctx->ws_lncnt.as<uint32_t>() + (size_t)((b0 + 3) / 4 * 4);   // (a second half starts on a 16-byte boundary)
-  ws.ln_part = ctx->ws_lnpart.as<float>() + (size_t)b0 * 4 * 256 * 2;
+  ws.ln_part = ctx->ws_lnpart.as<float>() + (size_t)b0 * 4 * 256 * 4;
   ws.ln_spin = ctx->ln_spin;
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
@@ -982,6 +982,16 @@ int hvla_debug_train_gemm_exact(int on) {
 }
 // shader-clock stamps of the last context-encoder launch (workgroup 0): see hypernet.hip CTX_STAMP
 int hvla_debug_ctx_stamps(unsigned long long* out) { return debug_ctx_stamps(out) == hipSuccess ? HVLA_OK : HVLA_E_HIP; }
+// device pointer and size of one encoder workspace buffer (tools/ read intermediates back with hipMemcpy):
+// 0 x (f32 residual stream), 1 h (16-bit LayerNorm / attention output), 2 qkv, 3 g (MLP hidden), 4 corr, 5 abar, 6 ln_cnt, 7 ln_part
+int hvla_debug_workspace(hvla_ctx* ctx, int which, void** ptr, size_t* bytes) {
+  if (!ctx || !ptr || !bytes) return HVLA_E_STATE;
+  DevBuf* b[8] = {&ctx->ws_x, &ctx->ws_h, &ctx->ws_qkv, &ctx->ws_g, &ctx->ws_corr, &ctx->ws_abar, &ctx->ws_lncnt, &ctx->ws_lnpart};
+  if (which < 0 || which > 7) return HVLA_E_SHAPE;
+  *ptr = b[which]->p;
+  *bytes = b[which]->bytes;
+  return HVLA_OK;
+}
 int hvla_debug_lnx_stats(hvla_ctx* ctx, unsigned long long* out, int reset) {
   if (!ctx) return HVLA_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -122,8 +122,9 @@ struct GemmArgs {
   void* ln_abar = nullptr;       // 16-bit [B][2][N] (nullable)
   uint32_t* ln_cnt = nullptr;    // [B]: bits 0-15 column tiles arrived since the call's memset (ln_target = launch number x nbn),
                                  //      bit 16 + c: column tile c of this launch was abandoned
-  float* ln_part = nullptr;      // [B][nbn][256][2] f32
-  uint32_t ln_target = 0;
+  float* ln_part = nullptr;      // [B][nbn][256] entries {sum, tag, sum of squares, tag}: 16 bytes, zero when the call starts
+  uint32_t ln_target = 0;        // launch number (1, 2, ...) x nbn: the count of a complete image
+  uint32_t ln_tag = 0;           // launch number: the tag of this launch's entries in ln_part
   uint32_t ln_spin = 0;          // bound of the wait, in ticks of the 100 MHz constant clock
   uint32_t out_bytes = 0;        // size of `out` in bytes (buffer descriptor of the write-through stores)
   uint32_t part_bytes = 0;       // size of ln_part in bytes
@@ -1037,16 +1038,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
   // few dozen workgroups per XCD / rounds there are; G, R / nbn and the images per XCD label come from the host as well)
   bool later = false;
   int rnd = 0;                                       // tiles this workgroup has started
+  int pend_img = -1;                                 // LNX: the workgroup's previous tile has not counted itself in yet (image, its mark)
+  uint32_t pend_mark = 0;
   auto tile_origin_x = [&](int& tm, int& n0, bool& lat) {
+    typedef const __attribute__((address_space(4))) GemmArgs* karg_ptr;     // (re-read from the kernarg segment: not kept in SGPRs across the K loops)
+    karg_ptr ga = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ga));
     const int xcd = (int)blockIdx.x & 7, w = (int)blockIdx.x >> 3;
-    const int G = g.lnx_G, wq = (w * g.lnx_rcp) >> 16, rq = (rnd * g.lnx_rcp) >> 16;
+    const int G = ga->lnx_G, rcp = ga->lnx_rcp, wq = (w * rcp) >> 16, rq = (rnd * rcp) >> 16;
     int row, col;
     if (wq < G) {
       row = rnd * G + wq; col = w - wq * nbn; lat = false;
     } else {
-      row = g.lnx_rows_aligned + (w - G * nbn) * g.lnx_rounds_div + rq; col = rnd - rq * nbn; lat = col != nbn - 1;
+      row = ga->lnx_rows_aligned + (w - G * nbn) * ga->lnx_rounds_div + rq; col = rnd - rq * nbn; lat = col != nbn - 1;
     }
-    tm = xcd * g.lnx_rows_xcd + row;
+    tm = xcd * ga->lnx_rows_xcd + row;
     n0 = col * HBN_;
     ++rnd;
   };
@@ -1199,8 +1205,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     const float* brow = (EPI != EPI_PATCH && g.corr) ? g.corr + ((size_t)ctm * 2 + wm) * g.N : g.bias;   // this wave row's half of the image
     const bool wvalid = cn0 + wn * 64 < g.N;          // (wave-uniform) this wave's 64 columns exist
     f32x4 pb4 = f32x4{0.f, 0.f, 0.f, 0.f}, pl4 = pb4;
+    // LNX: the lane id comes from the hardware again (mbcnt) -- nothing per-lane of this long epilogue is a register across the K loops
+    int lane_e = lane;
+#ifndef HVLA_EXP_NOMBCNT
+    if constexpr (LNX) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));   // (volatile: recomputed per tile, not hoisted)
+#endif
+    const int fr_e = LNX ? (lane_e & 15) : fr;
     if (wvalid) {
-      const uint32_t vcol = (uint32_t)(cn0 + wn * 64 + 4 * fr);     // 32-bit lane offset on a uniform base: no 64-bit lane address kept across the K loop
+      const uint32_t vcol = (uint32_t)(cn0 + wn * 64 + 4 * fr_e);     // 32-bit lane offset on a uniform base: no 64-bit lane address kept across the K loop
       pb4 = *reinterpret_cast<const f32x4*>(brow + vcol);
       pl4 = pb4;
       if constexpr (EPI == EPI_RES) pl4 = *reinterpret_cast<const f32x4*>(g.aux + vcol);
@@ -1257,9 +1269,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       typedef __attribute__((address_space(3))) float lds_f;
       typedef __attribute__((address_space(3))) f32x4 lds_f4;
       typedef __attribute__((address_space(3))) uint32_t lds_u;
-      lds_f* stat = (lds_f*)((lds_char*)smem + LNX_STAT);
-      lds_f* mr = (lds_f*)((lds_char*)smem + LNX_MR);
-      volatile lds_u* ctrl = (volatile lds_u*)((lds_char*)smem + LNX_CTRL);
+      // (opaque copies: what derives from them is computed inside this block, not in front of the tile loop -- hoisted, even the
+      // constant LDS addresses below end up as spilled SGPRs)
+      uint32_t lds_x = LNX_STAT;
+      int nbn_x = nbn, wm_x = wm, wn_x = wn;
+#ifndef HVLA_EXP_NOOPQ
+      asm volatile("" : "+s"(lds_x), "+s"(nbn_x), "+s"(wm_x), "+s"(wn_x));
+#endif
+      lds_f* stat = (lds_f*)((lds_char*)smem + lds_x);
+      lds_f* mr = (lds_f*)((lds_char*)smem + lds_x + (LNX_MR - LNX_STAT));
+      volatile lds_u* ctrl = (volatile lds_u*)((lds_char*)smem + lds_x + (LNX_CTRL - LNX_STAT));
       const int img = ctm, ct = cn0 / HBN_;
       // the arguments are re-read from the kernarg segment behind an opaque pointer: none of them is kept in an SGPR across the K loops
       typedef const __attribute__((address_space(4))) GemmArgs* karg_ptr;
@@ -1267,10 +1286,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       asm volatile("" : "+s"(gp));
       // an opaque copy of the thread id: nothing this block derives from it can be computed in front of the K loop and kept in
       // registers across it (the K loop has none to spare)
-      int tid_x = tid;
+      int tid_x = wave * 64 + lane_e;
       asm volatile("" : "+v"(tid_x));
       const int lane_x = tid_x & 63, fr_x = lane_x & 15, fq_x = lane_x >> 4;
-      const uint32_t row0 = (uint32_t)(img * gp->S + 1 + wm * 128 + 4 * fq_x);        // global row of this lane_x's (mt, r) = (0, 0)
+      const uint32_t row0 = (uint32_t)(img * gp->S + 1 + wm_x * 128 + 4 * fq_x);        // global row of this lane's (mt, r) = (0, 0)
+      // the previous tile of this workgroup counts itself in now (see [F]): its stores completed during the K loop
+      uint32_t pend_old = 0;
+      if constexpr (PERSIST) {
+        if (pend_img >= 0 && tid_x == 0)
+          pend_old = __hip_atomic_fetch_add(gp->ln_cnt + pend_img, 1u + pend_mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       const float invE = 1.f / (float)gp->N;
 #ifdef HVLA_BENCH_HOOKS
       const unsigned long long dbg_t0 = __builtin_readcyclecounter();
@@ -1281,7 +1306,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       // x and h are addressed as buffers: ONE per-lane_x offset (the lane_x's row (mt, r) = (0, 0), its four columns) plus a scalar
       // row offset per access -- no per-row address registers beside the 128 of xk
       const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(gp->out, 0, (int)gp->out_bytes, 0x00020000);
-      const uint32_t lane_e = row0 * (uint32_t)gp->N + (uint32_t)(wn * 64 + 4 * fr_x);     // element offset of (row0, this lane_x's columns of a tile at column 0)
+      const uint32_t lane_el = row0 * (uint32_t)gp->N + (uint32_t)(wn_x * 64 + 4 * fr_x);     // element offset of (row0, this lane_x's columns of a tile at column 0)
       f32x4 xk[8][4];                                    // [mt][r]: x of row 16 mt + 4 fq + r of the wave's 128, columns 4 fr .. 4 fr + 3 of its 64
       {                                                  // (every wave: one whose 64 columns do not exist computes on zeros / whatever the
                                                          // next row holds, counts as zeros below and stores nothing -- a branch here would
@@ -1290,10 +1315,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         // one m-tile (four rows) at a time, two m-tiles requested ahead: 8-12 loads in flight.  The accumulators of an m-tile die
         // where its four rows of xk are born (the K loop runs at the register limit: there is no room for both arrays).
         __amdgpu_buffer_rsrc_t irs = xrs;
-        uint32_t ivo = (lane_e + (uint32_t)cn0) * 4u;
+        uint32_t ivo = (lane_el + (uint32_t)cn0) * 4u;
         if constexpr (EPI == EPI_PATCH) {
           irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp->aux), 0, gp->S * gp->N * 4, 0x00020000);
-          ivo = ((uint32_t)(1 + wm * 128 + 4 * fq_x) * (uint32_t)gp->N + (uint32_t)(cn0 + wn * 64 + 4 * fr_x)) * 4u;
+          ivo = ((uint32_t)(1 + wm_x * 128 + 4 * fq_x) * (uint32_t)gp->N + (uint32_t)(cn0 + wn_x * 64 + 4 * fr_x)) * 4u;
         }
         const float q = gp->qscale;
         f32x4 xin[3][4];                                 // a ring of three m-tiles
@@ -1333,9 +1358,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       const unsigned long long dbg_tA = __builtin_readcyclecounter();
 #endif
       // [B] (sum, sum of squares) of every row over this wave's 64 columns -> LDS; the four waves of a wave row -> the tile's
-      // partial of the row -> ln_part (write-through); drain; one lane counts the tile in
+      // partial of the row, published as ONE 16-byte entry {S, tag, Q, tag} (write-through; tag = this launch's number in the call,
+      // the table is zeroed when the call starts): whoever reads an entry with both tags right has the row's two sums
       const float vmask = wvalid ? 1.f : 0.f;
-#ifndef HVLA_T_NOSTATS
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         float sv[4], qv[4];
@@ -1346,41 +1371,44 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
           qv[r] = row16_sum(qv[r]) * vmask;
         }
         if (fr_x == 0) {
-          lds_f4* d = (lds_f4*)(stat + (wn * 256 + wm * 128 + 16 * mt + 4 * fq_x) * 2);
+          lds_f4* d = (lds_f4*)(stat + (wn_x * 256 + wm_x * 128 + 16 * mt + 4 * fq_x) * 2);
           d[0] = f32x4{sv[0], qv[0], sv[1], qv[1]};
           d[1] = f32x4{sv[2], qv[2], sv[3], qv[3]};
         }
         __builtin_amdgcn_sched_barrier(0);               // one m-tile's eight reductions at a time (register pressure)
       }
-#endif
       HVLA_LBAR();
-      if (tid_x < 256) {
-        typedef float f2 __attribute__((ext_vector_type(2)));
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(gp->ln_part, 0, (int)gp->part_bytes, 0x00020000);
+      const uint32_t tag = gp->ln_tag;
+      auto ent = [](u32x4 e) { const f32x4 f = __builtin_bit_cast(f32x4, e); return f2{f[0], f[2]}; };   // (sum, sum of squares) of an entry
+      // thread t and thread t + 256 both hold the tile's partial of row t: the lower wave row publishes it, the upper one reads
+      // the other tiles' (a wave that has just stored gets no load back before its store has completed: vmcnt retires in order)
+      const int prow = tid_x & 255;
+      f2 mine;
+      {
         typedef __attribute__((address_space(3))) f2 lds_f2;
-        const f2 p0 = *(lds_f2*)(stat + (0 * 256 + tid_x) * 2), p1 = *(lds_f2*)(stat + (1 * 256 + tid_x) * 2);
-        const f2 p2 = *(lds_f2*)(stat + (2 * 256 + tid_x) * 2), p3 = *(lds_f2*)(stat + (3 * 256 + tid_x) * 2);
-        const f2 pt = (p0 + p1) + (p2 + p3);
-        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(gp->ln_part, 0, (int)gp->part_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pt), prs, (int)((uint32_t)((img * nbn + ct) * 256 + tid_x) * 8u), 0, 16);   // aux 16 = sc1
+        const f2 p0 = *(lds_f2*)(stat + (0 * 256 + prow) * 2), p1 = *(lds_f2*)(stat + (1 * 256 + prow) * 2);
+        const f2 p2 = *(lds_f2*)(stat + (2 * 256 + prow) * 2), p3 = *(lds_f2*)(stat + (3 * 256 + prow) * 2);
+        mine = (p0 + p1) + (p2 + p3);
       }
-      // scale / bias of the LayerNorm for this lane_x's four columns: requested here (the residual rows' registers are free again),
-      // waited for with the partials
+      if (tid_x < 256) {
+        // (as a float vector: u32x4{bit_cast(mine[0]), tag, bit_cast(mine[1]), tag} came out of hipcc 7.2 with mine[0] twice)
+        const float tagf = __builtin_bit_cast(float, tag);
+        const f32x4 ef = f32x4{mine[0], tagf, mine[1], tagf};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ef), prs, (int)((uint32_t)((img * nbn_x + ct) * 256 + prow) * 16u), 0, 16);   // aux 16 = sc1
+      }
+      // scale / bias of the LayerNorm for this lane's four columns (the residual rows' registers are free again)
       f32x4 lg4 = f32x4{0.f, 0.f, 0.f, 0.f}, lb4 = lg4;
       if (wvalid) {
-        const uint32_t vcol = (uint32_t)(cn0 + wn * 64 + 4 * fr_x);
+        const uint32_t vcol = (uint32_t)(cn0 + wn_x * 64 + 4 * fr_x);
         lg4 = *reinterpret_cast<const f32x4*>(gp->ln_scale + vcol);
         lb4 = *reinterpret_cast<const f32x4*>(gp->ln_bias + vcol);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials are at the memory side (and the next tile's prologue DMA has landed)
-      asm volatile("" : "+v"(lg4), "+v"(lb4));
-      HVLA_LBAR();
       const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(gp->ln_out, 0, (int)(gp->out_bytes / 4u * (uint32_t)sizeof(T)), 0x00020000);
       auto store_x = [&]() {                             // the new residual rows, write-through: an abandoned tile is read back by another workgroup
         if (!wvalid) return;
-#ifdef HVLA_T_NOSTOREX
-        return;
-#endif
-        const uint32_t vo = (lane_e + (uint32_t)cn0) * 4u;
+        const uint32_t vo = (lane_el + (uint32_t)cn0) * 4u;
         int rowb = gp->N * 4;
         asm volatile("" : "+s"(rowb));
 #pragma unroll
@@ -1392,43 +1420,52 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 #ifdef HVLA_BENCH_HOOKS
       const unsigned long long dbg_tB = __builtin_readcyclecounter();
 #endif
-      // [C] wave 0 counts the tile in and finds out about the image's other column tiles; the other waves store x meanwhile, and
-      // wave 1 normalises this tile's 256 columns of the image's CLS row (x[img * S] was finished by an earlier launch)
-      enum { LNX_GO = 0, LNX_LAST = 1, LNX_ABANDON = 2 };
-      if (wave == 0) {
-#ifdef HVLA_BENCH_HOOKS
-        const unsigned long long dbg_t1 = __builtin_readcyclecounter();
-#endif
-        uint32_t old = 0;
-        if (lane_x == 0) old = __hip_atomic_fetch_add(gp->ln_cnt + img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = __builtin_amdgcn_readfirstlane(old);
-        uint32_t status = LNX_ABANDON, abn = 0;
-        if ((old & 0xffffu) + 1u >= gp->ln_target) {
-          status = LNX_LAST;
-          abn = old >> 16;
-        } else if (!clater) {
+      // [C] threads 256-511 (the upper wave row) read the other column tiles' entries of their row until the tags are right -- a few
+      // microseconds of skew between workgroups that started together -- or the bound runs out / the partners are known to be a
+      // round away (`later`): then this tile does not wait (its mark in [F]).  The lower wave row stores x meanwhile, and wave 0
+      // normalises this tile's 256 columns of the image's CLS row (x[img * S] was finished by an earlier launch).
+      if (wave >= 4) {
+        bool ok = !clater;
+        f2 t = mine;
+        if (ok) {
           const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+          const uint32_t eo = (uint32_t)(img * nbn_x * 256 + prow) * 16u;
           while (true) {
-            uint32_t v = 0;
-            if (lane_x == 0) v = __hip_atomic_load(gp->ln_cnt + img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v = __builtin_amdgcn_readfirstlane(v);
-            if ((v & 0xffffu) >= gp->ln_target) { status = LNX_GO; break; }
+            u32x4 pe[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < nbn_x) pe[c] = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)eo, c * 4096, 16);      // (this tile's own entry may not have landed: `mine`)
+            ok = true;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < nbn_x && c != ct) ok = ok && pe[c][1] == tag && pe[c][3] == tag;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) {
+              f2 pv[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) pv[c] = c == ct ? mine : ent(pe[c]);
+              t = pv[0];                                                                               // column tiles in ascending order
+#pragma unroll
+              for (int c = 1; c < 4; ++c)
+                if (c < nbn_x) t += pv[c];
+              break;
+            }
             if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)gp->ln_spin) break;
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        if (status != LNX_ABANDON) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool wave_ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+        if (wave_ok) {
+          float mean, rstd;
+          ln_finish(t[0], t[1], invE, mean, rstd);
+          *(__attribute__((address_space(3))) f2*)(mr + prow * 2) = f2{mean, rstd};
         }
-        if (lane_x == 0) ctrl[0] = status, ctrl[1] = abn;
+        if (lane_x == 0) ctrl[wave - 4] = wave_ok ? 1u : 0u;
 #ifdef HVLA_BENCH_HOOKS
-        dbg_wait = __builtin_readcyclecounter() - dbg_t1;
+        if (tid_x == 256) ctrl[6] = (uint32_t)(__builtin_readcyclecounter() - dbg_tB);
 #endif
       } else {
         store_x();
-#ifndef HVLA_T_NOCLS
-        if (wave == 1) {
+        if (wave == 0) {
           const int n4 = gp->N / 4;
           const f32x4* xr = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(gp->out) + (size_t)img * gp->S * gp->N);
           f32x4 cur[4];
@@ -1436,132 +1473,140 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
           for (int i = 0; i < 4; ++i) cur[i] = lane_x + 64 * i < n4 ? xr[lane_x + 64 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
           float mean, rstd;
           ln_row_stats<4>(cur, invE, mean, rstd);
-          const f32x4 mine = ct == 0 ? cur[0] : (ct == 1 ? cur[1] : (ct == 2 ? cur[2] : cur[3]));
+          const f32x4 mv = ct == 0 ? cur[0] : (ct == 1 ? cur[1] : (ct == 2 ? cur[2] : cur[3]));
           const int col = lane_x + 64 * ct;
           if (col < n4) {
             const f32x4 s4 = reinterpret_cast<const f32x4*>(gp->ln_scale)[col], b4 = reinterpret_cast<const f32x4*>(gp->ln_bias)[col];
             typename Op::x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (T)ln_value(mine[j], mean, rstd, s4[j], b4[j]);
+            for (int j = 0; j < 4; ++j) o[j] = (T)ln_value(mv[j], mean, rstd, s4[j], b4[j]);
             reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_out) + (size_t)img * gp->S * gp->N)[col] = o;
           }
         }
-#endif
       }
+      asm volatile("" : "+v"(lg4), "+v"(lb4));
       HVLA_LBAR();
-      uint32_t status = ctrl[0], abn = ctrl[1];
-      if (wave == 0) store_x();
-      if (status == LNX_ABANDON) {
-        // not waiting: x of this tile to the memory side, then the mark -- unless everybody has arrived meanwhile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        HVLA_LBAR();                                     // (also: every wave has read ctrl)
-        if (wave == 0) {
-          uint32_t old = 0;
-          if (lane_x == 0) old = __hip_atomic_fetch_or(gp->ln_cnt + img, 0x10000u << ct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          old = __builtin_amdgcn_readfirstlane(old);
-          uint32_t st2 = LNX_ABANDON;
-          if ((old & 0xffffu) >= gp->ln_target) {          // the last arriver did not see the mark: take it back, normalise here
-            if (lane_x == 0) __hip_atomic_fetch_and(gp->ln_cnt + img, ~(0x10000u << ct), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            st2 = LNX_GO;
-          }
-          if (lane_x == 0) ctrl[0] = st2;
-        }
-        HVLA_LBAR();
-        status = ctrl[0];
-      }
+      const bool go = (ctrl[0] & ctrl[1] & ctrl[2] & ctrl[3]) != 0u;   // every row of the tile has its statistics
+      if (wave >= 4) store_x();
 #ifdef HVLA_BENCH_HOOKS
+      dbg_wait = ctrl[6];
       unsigned long long dbg_slow = 0;
       const unsigned long long dbg_tC = __builtin_readcyclecounter();
 #endif
-      if (status != LNX_ABANDON) {
-        // [D] the image's partials in column-tile order -> (mean, rstd) of this tile's 256 rows
+      // [E] normalise from the registers: h (16-bit) and this wave's 64 columns of the wave row's mean row.  `im`: the image the
+      // rows in xk and (mean, rstd) in LDS belong to.
+      auto sweep = [&](int im, int ctile, f32x4 gm4, f32x4 bt4) {
+        const uint32_t ncol = (uint32_t)(ctile * HBN_ + wn_x * 64 + 4 * fr_x);
+        const uint32_t vo = ((uint32_t)(im * gp->S + 1 + wm_x * 128 + 4 * fq_x) * (uint32_t)gp->N + ncol) * (uint32_t)sizeof(T);
+        int rowb = gp->N * (int)sizeof(T);
+        asm volatile("" : "+s"(rowb));
+        f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          const lds_f4* mp = (const lds_f4*)(mr + (wm_x * 128 + 16 * mt + 4 * fq_x) * 2);
+          const f32x4 m01 = mp[0], m23 = mp[1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float mean = r < 2 ? m01[2 * r] : m23[2 * r - 4], rstd = r < 2 ? m01[2 * r + 1] : m23[2 * r - 3];
+            typename Op::x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float y = ln_value(xk[mt][r][c], mean, rstd, gm4[c], bt4[c]);
+              cs[c] = (mt == 0 && r == 0) ? y : cs[c] + y;                     // ascending rows
+              o[c] = (T)y;
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), hrs, (int)vo, (16 * mt + r) * rowb, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (gp->ln_abar) {
+          typename Op::x4 mo;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float t = cs[c];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);                                        // (p0 + p1) + (p2 + p3)
+            mo[c] = (T)(t * (1.f / 128.f));
+          }
+          if (fq_x == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_abar) + ((size_t)im * 2 + wm_x) * gp->N + ncol) = mo;
+        }
+      };
+      if (go && wvalid) sweep(img, ct, lg4, lb4);
+      // [F] book-keeping, off the critical path.  Every tile adds itself ONCE to its image's word (bits 0-15: tiles arrived; bit
+      // 16 + c: column tile c did not wait) when its stores -- partial, x, h -- have completed: in the persistent form at the start
+      // of the workgroup's NEXT epilogue (a whole K loop later: nothing to wait for), its answer read at the end of that epilogue; a
+      // workgroup's last tile drains and adds at once.  The tile whose add completes the image finds the marks of the tiles that
+      // did not wait and normalises them from memory (their x and every partial are there: each add follows its tile's stores).
+      auto from_memory = [&](int im, uint32_t bits) {      // workgroup-uniform; the image's (mean, rstd) again, then the marked tiles
+        if (wave == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        HVLA_LBAR();
         if (tid_x < 256) {
-          typedef float f2 __attribute__((ext_vector_type(2)));
-          f2 pp[4];
+          const uint32_t eo = (uint32_t)(im * nbn_x * 256 + tid_x) * 16u;
+          u32x4 pe[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            if (c < nbn) pp[c] = *reinterpret_cast<const f2*>(gp->ln_part + (size_t)((img * nbn + c) * 256 + tid_x) * 2);
-          f2 t = pp[0];
+            if (c < nbn_x) pe[c] = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)eo, c * 4096, 0);
+          f2 t = ent(pe[0]);
 #pragma unroll
           for (int c = 1; c < 4; ++c)
-            if (c < nbn) t += pp[c];
+            if (c < nbn_x) t += ent(pe[c]);
           float mean, rstd;
           ln_finish(t[0], t[1], invE, mean, rstd);
           *(__attribute__((address_space(3))) f2*)(mr + tid_x * 2) = f2{mean, rstd};
         }
         HVLA_LBAR();
-        // [E] normalise from the registers: h (16-bit) and this wave's 64 columns of the wave row's mean row
-        auto sweep = [&](int ctile, f32x4 gm4, f32x4 bt4) {
-          const uint32_t ncol = (uint32_t)(ctile * HBN_ + wn * 64 + 4 * fr_x);
-          const uint32_t vo = (lane_e + (uint32_t)(ctile * HBN_)) * (uint32_t)sizeof(T);
-          int rowb = gp->N * (int)sizeof(T);
+        for (int c = 0; c < nbn_x; ++c) {
+          if (!((bits >> (16 + c)) & 1u) || c * HBN_ + wn_x * 64 >= gp->N) continue;       // (wave-uniform)
+          const uint32_t ncol = (uint32_t)(c * HBN_ + wn_x * 64 + 4 * fr_x);
+          const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gp->ln_scale + ncol), bt4 = *reinterpret_cast<const f32x4*>(gp->ln_bias + ncol);
+          const uint32_t vo = ((uint32_t)(im * gp->S + 1 + wm_x * 128 + 4 * fq_x) * (uint32_t)gp->N + ncol) * 4u;
+          int rowb = gp->N * 4;
           asm volatile("" : "+s"(rowb));
-          f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int mt = 0; mt < 8; ++mt) {
-            const lds_f4* mp = (const lds_f4*)(mr + (wm * 128 + 16 * mt + 4 * fq_x) * 2);
-            const f32x4 m01 = mp[0], m23 = mp[1];
+          for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float mean = r < 2 ? m01[2 * r] : m23[2 * r - 4], rstd = r < 2 ? m01[2 * r + 1] : m23[2 * r - 3];
-              typename Op::x4 o;
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const float y = ln_value(xk[mt][r][c], mean, rstd, gm4[c], bt4[c]);
-                cs[c] = (mt == 0 && r == 0) ? y : cs[c] + y;                     // ascending rows
-                o[c] = (T)y;
-              }
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), hrs, (int)vo, (16 * mt + r) * rowb, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (gp->ln_abar) {
-            typename Op::x4 mo;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              float t = cs[c];
-              t += __shfl_xor(t, 16, 64);
-              t += __shfl_xor(t, 32, 64);                                        // (p0 + p1) + (p2 + p3)
-              mo[c] = (T)(t * (1.f / 128.f));
-            }
-            if (fq_x == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_abar) + ((size_t)img * 2 + wm) * gp->N + ncol) = mo;
-          }
-        };
-#ifndef HVLA_T_NOSWEEP
-        if (wvalid) sweep(ct, lg4, lb4);
-#endif
-        // [F] the image's last arriver: the tiles that did not wait, from the x they stored
-#ifndef HVLA_T_NOSLOW
-        if (status == LNX_LAST && abn) {
+            for (int r = 0; r < 4; ++r)
+              xk[mt][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)vo, (16 * mt + r) * rowb, 0));
+          sweep(im, c, gm4, bt4);
 #ifdef HVLA_BENCH_HOOKS
-          dbg_slow = __builtin_popcount(abn);
+          ++dbg_slow;
 #endif
-          for (int c = 0; c < nbn; ++c) {
-            if (!((abn >> c) & 1u) || c * HBN_ + wn * 64 >= gp->N) continue;       // (wave-uniform)
-            const uint32_t ncol = (uint32_t)(c * HBN_ + wn * 64 + 4 * fr_x);
-            const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gp->ln_scale + ncol), bt4 = *reinterpret_cast<const f32x4*>(gp->ln_bias + ncol);
-            const uint32_t vo = (lane_e + (uint32_t)(c * HBN_)) * 4u;
-            int rowb = gp->N * 4;
-            asm volatile("" : "+s"(rowb));
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                xk[mt][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)vo, (16 * mt + r) * rowb, 0));
-            sweep(c, gm4, bt4);
-          }
-          if (tid_x == 0) __hip_atomic_fetch_and(gp->ln_cnt + img, 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the marks, for the next launch
         }
-#endif
+        if (tid_x == 0) __hip_atomic_fetch_and(gp->ln_cnt + im, 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the marks, for the next launch
+      };
+      auto settle = [&](int im, uint32_t mark, uint32_t old) {   // workgroup-uniform: `old` = what the add of tile (im, mark) returned (wave 0)
+        if (wave == 0) {
+          old = __builtin_amdgcn_readfirstlane(old);
+          const uint32_t bits = (old + 1u + mark);
+          if (lane_x == 0) ctrl[4] = ((bits & 0xffffu) >= gp->ln_target && (bits >> 16)) ? bits : 0u;
+        }
+        HVLA_LBAR();
+        const uint32_t bits = ctrl[4];
+        HVLA_LBAR();                                       // (read by every wave before it is written again)
+        if (bits) from_memory(im, bits);
+      };
+      const uint32_t my_mark = go ? 0u : (0x10000u << ct);
+      if constexpr (PERSIST) {
+        if (pend_img >= 0) settle(pend_img, pend_mark, pend_old);
+        pend_img = img;
+        pend_mark = my_mark;
+      }
+      if (!PERSIST || !more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's partial, x and h have completed
+        HVLA_LBAR();
+        uint32_t old = 0;
+        if (tid_x == 0) old = __hip_atomic_fetch_add(gp->ln_cnt + img, 1u + my_mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        settle(img, my_mark, old);
       }
 #ifdef HVLA_BENCH_HOOKS
       if (tid_x == 0 && blockIdx.x < 256) {
         atomicAdd(&g_lnx_dbg[0][blockIdx.x], 1ull);
         atomicAdd(&g_lnx_dbg[1][blockIdx.x], (unsigned long long)__builtin_readcyclecounter() - dbg_t0);
         atomicAdd(&g_lnx_dbg[2][blockIdx.x], dbg_wait);
-        if (status == LNX_ABANDON) atomicAdd(&g_lnx_dbg[3][blockIdx.x], 1ull);
+        if (!go) atomicAdd(&g_lnx_dbg[3][blockIdx.x], 1ull);
         if (dbg_slow) atomicAdd(&g_lnx_dbg[4][blockIdx.x], dbg_slow);
         atomicAdd(&g_lnx_dbg[5][blockIdx.x], dbg_tA - dbg_t0);
         atomicAdd(&g_lnx_dbg[6][blockIdx.x], dbg_tB - dbg_tA);
@@ -1570,7 +1615,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 #endif
 #undef HVLA_LBAR
       if (!more) break;
-      continue;                                          // (K-tile 0 of the next tile landed in front of the count-in: vmcnt(0) above)
+      // K-tile 0 of the next tile must have landed: its DMA is older than everything this epilogue issued -- 32 loads and 32 stores
+      // of x at least in a wave that has columns
+      if (wvalid) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      continue;
     }
     if (!more) break;
     // K-tile 0 of the next tile must have landed: its PRO_DMA_KT0 instructions are the oldest of the PRO_DMA + (epilogue)
@@ -2108,8 +2157,9 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   auto lnx_args = [&](GemmArgs& a, const float* ln_s, const float* ln_b, int nbn_) {
     a.ln_out = ws.h; a.ln_scale = ln_s; a.ln_bias = ln_b; a.ln_abar = comp ? ws.abar : nullptr; a.ln_cnt = ws.ln_cnt; a.ln_part = ws.ln_part;
     a.out_bytes = (uint32_t)((size_t)M * E * 4);
-    a.part_bytes = (uint32_t)((size_t)B * nbn_ * 256 * 2 * sizeof(float));
-    a.ln_target = ++ln_launch * (uint32_t)nbn_;
+    a.part_bytes = (uint32_t)((size_t)B * nbn_ * 256 * 16);
+    a.ln_tag = ++ln_launch;
+    a.ln_target = ln_launch * (uint32_t)nbn_;
     a.ln_spin = ws.ln_spin;
     if (lnx_persistent((int)a.nbm, nbn_)) {
       const int Wx = ncu / 8, R = a.nbm * nbn_ / ncu;
@@ -2254,7 +2304,10 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     hipLaunchKernelGGL((absmax_kernel<T>), dim3(1024), dim3(256), 0, st, reinterpret_cast<const T*>(buf), n / 8, audit + 2 * site);
   };
   // the images' arrival words of the fused LayerNorms: zero before the first launch of every call (a memset node when the call is captured)
-  if (can_fuse_ln && P == HBM_ && M > G64_MAXM && (e = hipMemsetAsync(ws.ln_cnt, 0, (size_t)((B * 4 + 15) / 16 * 16), st)) != hipSuccess) return e;
+  if (can_fuse_ln && P == HBM_ && M > G64_MAXM) {
+    if ((e = hipMemsetAsync(ws.ln_cnt, 0, (size_t)((B * 4 + 15) / 16 * 16), st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ws.ln_part, 0, (size_t)B * ((E + HBN_ - 1) / HBN_) * 256 * 16, st)) != hipSuccess) return e;   // the entries' tags
+  }
   using EQ = std::integral_constant<int, EPI_QKV>;
   using EG = std::integral_constant<int, EPI_GELU>;
   using ER = std::integral_constant<int, EPI_RES>;

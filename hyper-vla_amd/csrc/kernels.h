@@ -63,7 +63,7 @@ struct EncWorkspace {
   void* abar;      // [B, 2, max(E, F)] 16-bit mean rows (upper / lower half of the image) of the current GEMM's activation operand
   float* amap = nullptr;   // nullable: [B, enc_layers, enc_heads, P] attention of the CLS query over the patch keys (opt-in export)
   uint32_t* ln_cnt = nullptr;   // nullable: [B rounded up to 4] arrival words of the LayerNorms fused into the residual GEMMs (encoder.hip GemmArgs::ln_cnt)
-  float* ln_part = nullptr;     // nullable: [B][4][256][2] per-row (sum, sum of squares) of every column tile (GemmArgs::ln_part); either null = LayerNorm as its own launch
+  float* ln_part = nullptr;     // nullable: [B][<= 4][256] 16-byte entries, the per-row (sum, sum of squares) of every column tile (GemmArgs::ln_part); either null = LayerNorm as its own launch
   uint32_t ln_spin = 800;       // how long a column tile waits for the image's other tiles before it leaves its share to the last arriver: ticks of 10 ns
 };
 // optional live timing: a pool of hipEvent pairs tagged with a category (include/hvla.h HVLA_PROF_*)
