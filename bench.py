@@ -219,8 +219,6 @@ def main():
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2: hvla_step runs the two halves of the batch on two streams (more actions/s; per-kernel "
                          "durations then include time shared with the other half, so the roofline line is not comparable)")
-    ap.add_argument("--layernorm-tail", action="store_true",
-                    help="A/B only: norm1 / norm2 as tail jobs of the residual GEMMs instead of launches of their own (same bytes)")
     ap.add_argument("--ensemble", action="store_true",
                     help="include the device-side un-normalise + temporal ensemble in every step (always on with --graph)")
     ap.add_argument("--finetune", action="store_true",
@@ -255,8 +253,7 @@ def main():
     from hypervla.dp import max_over_ranks, whole_job_rate
     from hypervla.model import HyperVLA
     g, B = (SMALL_E if a.encoder == "small" else FULL), a.batch
-    model = HyperVLA.from_synthetic(g, device=local, max_batch=B, enc_dtype=a.enc_dtype, streams=a.streams,
-                                    layernorm_tail=a.layernorm_tail)
+    model = HyperVLA.from_synthetic(g, device=local, max_batch=B, enc_dtype=a.enc_dtype, streams=a.streams)
     dev = model.device
     if a.finetune:
         return finetune_bench(a, model, rank, world, use_dist)

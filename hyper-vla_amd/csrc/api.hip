@@ -113,6 +113,7 @@ const char* hvla_last_error(const hvla_ctx* ctx) { return ctx ? ctx->err.c_str()
 int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
   if (!c || !out) return HVLA_E_SHAPE;
   *out = nullptr;
+  if (c->struct_size != sizeof(hvla_config)) return HVLA_E_SHAPE;   // the caller's header is not this library's: never read past its struct
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return HVLA_E_DEVICE;
   hipDeviceProp_t prop;

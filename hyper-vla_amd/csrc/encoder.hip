@@ -1321,6 +1321,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
           ivo = ((uint32_t)(1 + wm_x * 128 + 4 * fq_x) * (uint32_t)gp->N + (uint32_t)(cn0 + wn_x * 64 + 4 * fr_x)) * 4u;
         }
         const float q = gp->qscale;
+        const float vmask = wvalid ? 1.f : 0.f;
         f32x4 xin[3][4];                                 // a ring of three m-tiles
         int rowb = gp->N * 4;                              // bytes per row; opaque at every site that forms the 32 scalar row offsets: shared, the
         asm volatile("" : "+s"(rowb));                   // compiler keeps all of them in SGPRs through the epilogue and spills a hundred others
@@ -1351,32 +1352,54 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
             xk[mt][r] = x;
             asm volatile("" : "+v"(xk[mt][r]));          // computed HERE (left alone, the arithmetic is sunk to its first use, far below,
           }                                              // and the 32 loads' destinations all stay live: spills)
+#ifndef HVLA_EXP_STATSLATE
+          // [B] (sum, sum of squares) of these four rows over this wave's 64 columns -> LDS, here, under the loads of the next
+          // m-tiles (this loop waits for memory with the VALU idle; as a phase of its own the reductions were 5 us per tile)
+          {
+            float sv[4], qv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              ln_lane_stats(xk[mt][r], sv[r], qv[r]);
+              sv[r] = row16_sum(sv[r]) * vmask;          // (x 1.0f is exact; x 0.0f of a finite number: an absent wave counts as zeros)
+              qv[r] = row16_sum(qv[r]) * vmask;
+            }
+            if (fr_x == 0) {
+              lds_f4* d = (lds_f4*)(stat + (wn_x * 256 + wm_x * 128 + 16 * mt + 4 * fq_x) * 2);
+              d[0] = f32x4{sv[0], qv[0], sv[1], qv[1]};
+              d[1] = f32x4{sv[2], qv[2], sv[3], qv[3]};
+            }
+          }
+#endif
           __builtin_amdgcn_sched_barrier(0);             // (m-tile mt + 3 is not requested before this one is done: registers)
         }
       }
 #ifdef HVLA_BENCH_HOOKS
       const unsigned long long dbg_tA = __builtin_readcyclecounter();
 #endif
-      // [B] (sum, sum of squares) of every row over this wave's 64 columns -> LDS; the four waves of a wave row -> the tile's
-      // partial of the row, published as ONE 16-byte entry {S, tag, Q, tag} (write-through; tag = this launch's number in the call,
-      // the table is zeroed when the call starts): whoever reads an entry with both tags right has the row's two sums
-      const float vmask = wvalid ? 1.f : 0.f;
+#ifdef HVLA_EXP_STATSLATE
+      {                                                  // A/B variant (tools/build_variants.sh): the statistics as a phase of their own
+        const float vmask = wvalid ? 1.f : 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        float sv[4], qv[4];
+        for (int mt = 0; mt < 8; ++mt) {
+          float sv[4], qv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ln_lane_stats(xk[mt][r], sv[r], qv[r]);
-          sv[r] = row16_sum(sv[r]) * vmask;              // (x 1.0f is exact; x 0.0f of a finite number: an absent wave counts as zeros)
-          qv[r] = row16_sum(qv[r]) * vmask;
+          for (int r = 0; r < 4; ++r) {
+            ln_lane_stats(xk[mt][r], sv[r], qv[r]);
+            sv[r] = row16_sum(sv[r]) * vmask;
+            qv[r] = row16_sum(qv[r]) * vmask;
+          }
+          if (fr_x == 0) {
+            lds_f4* d = (lds_f4*)(stat + (wn_x * 256 + wm_x * 128 + 16 * mt + 4 * fq_x) * 2);
+            d[0] = f32x4{sv[0], qv[0], sv[1], qv[1]};
+            d[1] = f32x4{sv[2], qv[2], sv[3], qv[3]};
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (fr_x == 0) {
-          lds_f4* d = (lds_f4*)(stat + (wn_x * 256 + wm_x * 128 + 16 * mt + 4 * fq_x) * 2);
-          d[0] = f32x4{sv[0], qv[0], sv[1], qv[1]};
-          d[1] = f32x4{sv[2], qv[2], sv[3], qv[3]};
-        }
-        __builtin_amdgcn_sched_barrier(0);               // one m-tile's eight reductions at a time (register pressure)
       }
+#endif
+      // the four waves of a wave row -> the tile's partial of the row, published as ONE 16-byte entry {S, tag, Q, tag}
+      // (write-through; tag = this launch's number in the call, the table is zeroed when the call starts): whoever reads an entry
+      // with both tags right has the row's two sums
       HVLA_LBAR();
       typedef float f2 __attribute__((ext_vector_type(2)));
       const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(gp->ln_part, 0, (int)gp->part_bytes, 0x00020000);

@@ -28,13 +28,13 @@ PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "
 
 
 class hvla_config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "enc_dim", "enc_layers", "enc_heads",
+    _fields_ = [("struct_size", C.c_uint32)] + \
+               [(n, C.c_int32) for n in ("image_size", "patch", "enc_dim", "enc_layers", "enc_heads",
                                          "enc_mlp", "dim", "layers", "heads", "mlp", "horizon",
                                          "action_dim")] + \
                [("tanh_scale", C.c_float), ("max_action", C.c_float)] + \
                [(n, C.c_int32) for n in ("ctx_dim", "ctx_layers", "ctx_heads", "ctx_mlp", "lang_tokens",
-                                         "lang_dim", "scale_context", "max_batch", "enc_dtype", "streams", "clip_target",
-                                         "layernorm_tail")]
+                                         "lang_dim", "scale_context", "max_batch", "enc_dtype", "streams", "clip_target")]
 
 
 class hvla_tensor_desc(C.Structure):
@@ -152,18 +152,17 @@ class NativeError(RuntimeError):
 class Context:
     """One hvla_ctx (one device)."""
 
-    def __init__(self, geometry, device: int = 0, max_batch: int = 256, enc_dtype: str = "f16", streams: int = 1,
-                 layernorm_tail: bool = False):
+    def __init__(self, geometry, device: int = 0, max_batch: int = 256, enc_dtype: str = "f16", streams: int = 1):
         self.lib = load_library()
         g = geometry
         if enc_dtype not in ("f16", "bf16"):
             raise ValueError("enc_dtype must be 'f16' or 'bf16'")
-        self.cfg = hvla_config(g.image_size, g.patch, g.enc_dim, g.enc_layers, g.enc_heads, g.enc_mlp,
+        self.cfg = hvla_config(C.sizeof(hvla_config), g.image_size, g.patch, g.enc_dim, g.enc_layers, g.enc_heads, g.enc_mlp,
                                g.dim, g.layers, g.heads, g.mlp, g.horizon, g.action_dim,
                                g.tanh_scale, g.max_action, g.ctx_dim, g.ctx_layers, g.ctx_heads, g.ctx_mlp,
                                g.lang_tokens, g.lang_dim, int(g.scale_context), int(max_batch),
                                HVLA_ENC_BF16 if enc_dtype == "bf16" else HVLA_ENC_F16, int(streams),
-                               int(getattr(g, "clip_target", True)), int(bool(layernorm_tail)))
+                               int(getattr(g, "clip_target", True)))
         self.geometry, self.device, self.max_batch, self.enc_dtype = g, device, max_batch, enc_dtype
         h = C.c_void_p()
         rc = self.lib.hvla_create(C.byref(self.cfg), device, C.byref(h))

@@ -82,7 +82,7 @@ class GeneratedWeights:
 class HyperVLA:
     def __init__(self, config: Dict, params: Dict[str, np.ndarray], example_batch: Optional[Dict] = None,
                  dataset_statistics: Optional[Dict] = None, device: int = 0, max_batch: int = 256,
-                 enc_dtype: str = "f16", streams: int = 1, layernorm_tail: bool = False, _shared_ctx=None):
+                 enc_dtype: str = "f16", streams: int = 1, _shared_ctx=None):
         torch = _torch()
         self.config = config
         self.params = params
@@ -95,8 +95,7 @@ class HyperVLA:
                                "and there is no CPU fallback")
         self.device = torch.device("cuda", device)
         self.max_batch, self.enc_dtype, self.streams = max_batch, enc_dtype, streams
-        self.layernorm_tail = layernorm_tail             # hvla_config.layernorm_tail: same bytes, opt-in (A/B runs and tests)
-        self._ctx = _native.Context(self.geometry, device, max_batch, enc_dtype, streams, layernorm_tail)
+        self._ctx = _native.Context(self.geometry, device, max_batch, enc_dtype, streams)
         want = hypernet_param_shapes(self.geometry)
         missing = [k for k in want if k not in params]
         if missing:
@@ -217,7 +216,7 @@ class HyperVLA:
             return HyperVLA(changes.get("config", self.config), changes.get("params", self.params),
                             changes.get("example_batch", self.example_batch),
                             changes.get("dataset_statistics", self.dataset_statistics),
-                            self.device.index or 0, self.max_batch, self.enc_dtype, self.streams, self.layernorm_tail)
+                            self.device.index or 0, self.max_batch, self.enc_dtype, self.streams)
         import copy
         other = copy.copy(self)
         for k, v in changes.items():

@@ -48,6 +48,10 @@ typedef struct hvla_weights hvla_weights; /* per-batch generated-weight arena (o
 /* Geometry of the path == the values the reference reads from config.json
  * (hypervla/model.py:152-163,197-200; README.md:33-61).                                        */
 typedef struct hvla_config {
+  uint32_t struct_size;                      /* = sizeof(hvla_config) of the header the caller was built against: hvla_create
+                                                returns HVLA_E_SHAPE when it is not this library's (the struct is passed by pointer
+                                                and grows at its end; a binder built against another header is refused, never
+                                                read past its end)                                                      */
   int32_t image_size, patch;                 /* 224, 14                                         */
   int32_t enc_dim, enc_layers, enc_heads, enc_mlp; /* DINOv2-base: 768, 12, 12, 3072            */
   int32_t dim, layers, heads, mlp;           /* generated vit_t: 64, 4, 4, 128                  */
@@ -65,10 +69,6 @@ typedef struct hvla_config {
                                                 >= 64 episodes on two streams, forked from / joined to the caller's  */
   int32_t clip_target;                       /* action_head_kwargs.clip_target (action_heads.py:408,499-500): the loss clips
                                                 the action target to +-max_action iff non-zero                        */
-  int32_t layernorm_tail;                    /* 0 (default): norm1 / norm2 of the image encoder are launches of their own;
-                                                1: they run as tail jobs of the GEMM that writes the residual stream (batches
-                                                of >= 8 images of 256 patches).  The same bytes either way (tests cross them);
-                                                measured slower by 0.3-0.5 ms per step at B = 256, so opt-in.   */
 } hvla_config;
 
 /* One named float32 tensor of the hypernetwork checkpoint, HOST memory, reference naming

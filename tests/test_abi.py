@@ -30,6 +30,33 @@ def test_library_exports_every_declared_symbol():
     _native.load_library()
 
 
+def test_config_struct_layout_is_the_header_s(tmp_path):
+    """The ctypes mirror of hvla_config against the C compiler's view of include/hvla.h: size and every field offset."""
+    import subprocess
+    from hypervla import _native
+    names = [n for n, _ in _native.hvla_config._fields_]
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"hvla.h\"\nint main(void) { printf(\"%zu\", sizeof(hvla_config));\n"
+    prog += "".join(f'printf(" %zu", offsetof(hvla_config, {n}));\n' for n in names) + "return 0; }\n"
+    (tmp_path / "l.c").write_text(prog)
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(tmp_path / "l.c"), "-o", str(tmp_path / "l")], check=True)
+    got = [int(x) for x in subprocess.run([str(tmp_path / "l")], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_native.hvla_config)
+    assert got[1:] == [getattr(_native.hvla_config, n).offset for n in names]
+    assert names[0] == "struct_size"
+
+
+def test_a_config_struct_of_another_size_is_refused():
+    """hvla_config.struct_size: a binder built against another header (a shorter or a longer struct) gets HVLA_E_SHAPE from
+    hvla_create before anything of the struct is read -- with or without a GPU (the struct used to be copied blindly)."""
+    from hypervla import _native
+    lib = _native.load_library()
+    cfg = _native.hvla_config()
+    for bad in (0, ctypes.sizeof(_native.hvla_config) - 4, ctypes.sizeof(_native.hvla_config) + 4):
+        cfg.struct_size = bad
+        h = ctypes.c_void_p()
+        assert lib.hvla_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1 and not h.value      # HVLA_E_SHAPE
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():

@@ -915,33 +915,75 @@ def test_tokens_are_the_same_whichever_gemm_kernel_computes_them():
     assert torch.equal(pair[1], ref[0]) and torch.equal(pair[0], last[0])
 
 
+def _encode_in_a_fresh_process(code, flavour=None):
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if flavour:
+        env["HVLA_LIBRARY_FLAVOUR"] = flavour
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_layernorm_tail_gives_the_bytes_of_the_separate_launch():
-    """hvla_config.layernorm_tail = 1 (opt-in): norm1 / norm2 as tail jobs of the GEMM that writes the residual stream (gemm256p_kernel<..., LNT>: write-through stores, one
-    ticket per column tile, the image's last tile normalises its 257 rows) against the default (the
-    stand-alone layernorm_img_kernel / layernorm_split_kernel launches): the same patch tokens bit for bit, at a batch below one
-    round of workgroups (one tile per workgroup), at a ragged one and at 256 (persistent grid), repeatedly (a stale read or a
-    missed ticket would be a timing matter) and with another stream's copy kernel loading the memory system."""
+def test_layernorm_inside_the_residual_gemms_gives_the_bytes_of_the_stand_alone_kernels():
+    """norm1 / norm2 at B >= 8 run inside the epilogue of the GEMM that writes the residual stream (gemm256p_kernel<..., LNX>: the
+    column tiles of an image exchange per-row (sum, sum of squares) and normalise from registers; csrc/encoder.hip), at B <= 7 in
+    layernorm_group_kernel.  Every image must get the same patch tokens bit for bit: at batches of one round of workgroups (one
+    tile per workgroup), ragged ones, 256 and 512 (persistent grid, tile_origin_x), repeatedly (a stale read or a missed entry
+    would be a timing matter) and with another stream's copy kernel loading the memory system."""
     _need_gpu()
     from hypervla.config import FULL
     from hypervla.model import HyperVLA
     from hypervla.synthetic import synthetic_images
-    B = 256
+    B = 512
     im = synthetic_images(B, FULL)[:, 0]
-    sep = HyperVLA.from_synthetic(FULL, max_batch=B)
-    ref = sep.encode_images(im).cpu()
-    del sep
-    m = HyperVLA.from_synthetic(FULL, max_batch=B, layernorm_tail=True)
-    for nb in (8, 9, 40, 255):
-        assert torch.equal(m.encode_images(im[:nb]).cpu(), ref[:nb]), nb
+    m = HyperVLA.from_synthetic(FULL, max_batch=B)
+    probe = (0, 1, 7, 100, 255, 256, 511)
+    ref = {i: m.encode_images(im[i:i + 1]).cpu()[0] for i in probe}
+    for nb in (8, 9, 40, 85, 86, 255, 256, 512):
+        tok = m.encode_images(im[:nb]).cpu()
+        for i in probe:
+            if i < nb:
+                assert torch.equal(tok[i], ref[i]), (nb, i)
     big = torch.empty(1 << 28, dtype=torch.uint8, device=m.device)
     side = torch.cuda.Stream(m.device)
+    first = m.encode_images(im[:256]).cpu()
     for rep in range(12):
         if rep >= 6:                                        # uneven load: 256 MB copies on another stream while the encoder runs
             with torch.cuda.stream(side):
                 for _ in range(8):
                     big[: 1 << 27].copy_(big[1 << 27:])
-        tok = m.encode_images(im).cpu()
+        tok = m.encode_images(im[:256]).cpu()
         side.synchronize()
-        assert torch.equal(tok, ref), rep
+        assert torch.equal(tok, first), rep
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_a_tile_that_does_not_wait_is_normalised_from_memory_with_the_same_bytes():
+    """The fused LayerNorm never blocks: a column tile whose partners do not show up within GemmArgs::ln_spin marks itself in the
+    image's word and goes on; the tile that completes the image normalises the marked tiles from the x they stored.  With the
+    bound set to 0 (hvla_debug_lnx_spin, libhvla_bench.so) NOBODY waits -- every tile takes that route -- and the tokens must be the
+    bytes of the product library's run, at a one-round batch, a ragged one and the persistent grid."""
+    _need_gpu()
+    code = """
+import ctypes as C, hashlib, sys, os
+sys.path.insert(0, os.path.join(os.getcwd(), "hyper-vla_amd")); sys.path.insert(0, os.getcwd())
+from hypervla.config import FULL
+from hypervla.model import HyperVLA
+from hypervla.synthetic import synthetic_images
+m = HyperVLA.from_synthetic(FULL, max_batch=256)
+if os.environ.get("HVLA_LIBRARY_FLAVOUR") == "bench":
+    m._ctx.lib.hvla_debug_lnx_spin.argtypes = [C.c_void_p, C.c_uint32]
+    assert m._ctx.lib.hvla_debug_lnx_spin(m._ctx.h, 0) == 0
+im = synthetic_images(256, FULL)[:, 0]
+for nb in (8, 40, 256):
+    for rep in range(2):
+        print(nb, hashlib.sha256(m.encode_images(im[:nb]).cpu().numpy().tobytes()).hexdigest())
+"""
+    product = _encode_in_a_fresh_process(code)
+    nobody_waits = _encode_in_a_fresh_process(code, "bench")
+    assert len(product.split()) == 12 and product == nobody_waits
