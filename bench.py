@@ -26,7 +26,7 @@ for p in (os.path.join(ROOT, "hyper-vla_amd"), ROOT):
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-PMC_ROUND = "r4"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
+PMC_ROUND = "r5"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
 PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
@@ -40,18 +40,27 @@ def fc1_main_rows(B, g):
     return M
 
 
-def launches_per_step(g, B):
-    """Kernel launches of one eager hvla_step (csrc/encoder.hip run_encoder + the policy): per encoder layer two LayerNorms, four
-    GEMMs and the attention, plus what the batch size adds -- B >= 8: a small-row launch in front of every GEMM (11 per layer; 13 up
-    to 64 images, where a LayerNorm is two launches); B <= 7: the GELU column means (8 per layer at B = 1, where the consumer GEMM
-    adds the LayerNorm partials up itself; 10 otherwise); plus im2col (+ CLS rows), patch GEMM, final LayerNorm and the policy."""
-    S = g.patches + 1
-    if B * S <= 2047:
-        one_round = ((B * S + 63) // 64) * (max(3 * g.enc_dim, g.enc_mlp) // 64) <= 256
-        per = 8 if one_round else 10
-    else:
-        per = 11 if B > 64 else 13
-    return per * g.enc_layers + 4
+def box_probe(ctx, dev):
+    """What THIS box sustains, measured in this process right before the timed region (the boxes of a pool differ by several
+    per cent, and the driver's one number per round lands on one of them): shader clock under a chip-wide MFMA loop and that
+    loop's TFLOP/s (hvla_box_probe: a probe kernel of its own in libhvla), and what a 1 GiB device-to-device copy moves."""
+    clock_mhz, mfma_tflops, probe_ms = ctx.box_probe(torch.cuda.current_stream(dev).cuda_stream)
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(4):
+        dst.copy_(src)
+    e1.record(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    copy_tbps = 4 * 2 * float(1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    del src, dst
+    return {"shader_clock_mhz_under_mfma": round(clock_mhz, 1), "mfma_probe_tflops": round(mfma_tflops, 1),
+            "mfma_probe_frac_of_peak": round(mfma_tflops / PEAK_TFLOPS, 4), "mfma_probe_ms": round(probe_ms, 3),
+            "copy_1gib_tbps": round(copy_tbps, 3),
+            "note": "probe kernels of their own, run in this process before the timed region: a step time is read against these"}
 
 
 def algorithmic_flops(g):
@@ -135,11 +144,13 @@ def finetune_bench(a, model, rank, world, use_dist):
     f32_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     roofline = {"bound": "mfma", "kernel": "bgemm3_kernel (csrc/train.hip): every dense product of the step, f32 operands split hi + lo "
                                            "while staged, THREE v_mfma_f32_32x32x16_bf16 per product (a_hi b_hi + a_hi b_lo + a_lo b_hi)",
-                "achieved": round(3.0 * f32_tflops, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(3.0 * f32_tflops / PEAK_TFLOPS, 4),
-                "f32_equivalent_tflops": round(f32_tflops, 2), "mfma_per_product": 3, "traffic": None,
+                "achieved": round(f32_tflops, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f32_tflops / PEAK_TFLOPS, 4),
+                "matrix_instruction_tflops": round(3.0 * f32_tflops, 2), "matrix_instruction_frac": round(3.0 * f32_tflops / PEAK_TFLOPS, 4),
+                "mfma_per_product": 3, "traffic": None,
                 "gemm_ms_per_step": round(gemm_ms / 2, 3), "gemm_launches_per_step": gemm_n // 2,
                 "gemm_flops_per_step_f32_equivalent": gemm_flops / 2,
-                "note": "achieved = matrix-instruction work (3 x the f32-equivalent 2MNK) / summed duration of the GEMM launches; "
+                "note": "achieved / frac = USEFUL work (f32-equivalent 2MNK) / summed duration of the GEMM launches against the bf16 peak; "
+                        "the matrix cores execute three instructions per product (matrix_instruction_*); "
                         "the rest of the step is element-wise kernels and the optimiser"}
     if rank == 0:
         print(json.dumps({
@@ -287,8 +298,12 @@ def main():
             ctx.ensemble(w._h, actions.data_ptr(), ens[0].data_ptr(), ens[1].data_ptr(), ens[2].data_ptr(),
                          ens[3].data_ptr(), stream)
 
+    box = box_probe(ctx, dev) if rank == 0 else None
     for _ in range(a.warmup):
         step()
+    ctx.launches()
+    step()
+    launches = ctx.launches()         # what the library enqueued for one eager step (hvla_launches)
     eager_step = step
     if a.graph:                        # capture one step (launches only, no allocation / sync inside hvla_step)
         torch.cuda.synchronize(dev)
@@ -326,8 +341,9 @@ def main():
 
     # ---- per-step latency distribution + full kernel breakdown (separate, un-timed passes)
     lat = []
-    # p50 over >= 200 samples for a replayed graph (config 3) and for the small batches whose metric IS the latency (B <= 8)
-    n_lat = max(a.steps, 200) if (a.graph or B <= 8) else min(a.steps, 20)
+    # p50 over >= 200 samples for a replayed graph (config 3) and for the small batches whose metric IS the latency (B <= 8),
+    # over >= 100 at the headline batch (30 for the 60-120 ms steps of 1024 / 2048 episodes)
+    n_lat = max(a.steps, 200) if (a.graph or B <= 8) else max(a.steps, 100 if B <= 512 else 30)
     for _ in range(n_lat):
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -391,10 +407,11 @@ def main():
                    "encoder_operands": a.enc_dtype + " (+ per-image first-order compensation of the weight rounding, "
                                        "kernel_ms_per_step.small_row_gemms)",
                    "policy_operands": "split-bf16 (bf16x3)",
-                   "launch": "hipGraph replay" if a.graph else f"eager ({launches_per_step(g, B)} launches per step)",
+                   "launch": "hipGraph replay" if a.graph else f"eager ({launches} launches per step, counted by the library)",
                    "streams": a.streams,
                    "ensemble": "device-side un-normalise + temporal ensemble (history = horizon) inside the step"
                                if ens is not None else "not in the step"},
+        "box": box,
         "latency_samples": len(lat),
         "p50_step_latency_ms": round(float(np.median(lat)), 4),
         "roofline": {"bound": "mfma", "kernel": ("gemm64_kernel" if rows <= 2047 else "gemm256p_kernel") + f"<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",

@@ -565,6 +565,7 @@ static int policy_range(hvla_ctx* ctx, const hvla_weights* w, const float* token
                  nb, g.E, g.P(), g.L, g.M, g.horizon, g.action_dim, g.tanh_scale, g.max_action};
   if (ctx->amap_head) p.amap = ctx->amap_head + (size_t)b0 * g.L * g.H * g.P();
   ctx->prof.begin(HVLA_PROF_POLICY, st);
+  ++ctx->prof.nlaunch;
   HIPCHK(ctx, launch_policy(p, st));
   ctx->prof.end(HVLA_PROF_POLICY, st);
   return HVLA_OK;
@@ -626,6 +627,7 @@ int hvla_ensemble(hvla_ctx* ctx, hvla_weights* w, const float* actions, const fl
   if (!ctx || !w) return HVLA_E_STATE;
   if (!actions || !mean || !std || !mask || !out) FAIL(ctx, HVLA_E_SHAPE, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  ++ctx->prof.nlaunch;
   HIPCHK(ctx, launch_ensemble(actions, w->ring.as<float>(), w->count.as<int>(), mean, std, mask, out, w->B,
                               ctx->g.horizon, ctx->g.action_dim, reinterpret_cast<hipStream_t>(stream)));
   return HVLA_OK;
@@ -1007,6 +1009,24 @@ int hvla_debug_lnx_spin(hvla_ctx* ctx, uint32_t ticks) {
   return HVLA_OK;
 }
 #endif  // HVLA_BENCH_HOOKS
+
+int64_t hvla_launches(hvla_ctx* ctx) {
+  if (!ctx) return 0;
+  const int64_t n = (int64_t)ctx->prof.nlaunch;
+  ctx->prof.nlaunch = 0;
+  return n;
+}
+
+int hvla_box_probe(hvla_ctx* ctx, float out[3], void* stream) {
+  if (!ctx || !out) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf sink, ticks;
+  int ncu = 256;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  if (sink.alloc((size_t)ncu * 512 * sizeof(float)) != hipSuccess || ticks.alloc(64) != hipSuccess) FAIL(ctx, HVLA_E_ARENA_FULL, "box probe buffers");
+  HIPCHK(ctx, run_box_probe(sink.as<float>(), ticks.as<unsigned long long>(), out, reinterpret_cast<hipStream_t>(stream)));
+  return HVLA_OK;
+}
 
 int hvla_selftest(hvla_ctx* ctx, void* stream) {
   if (!ctx) return HVLA_E_STATE;

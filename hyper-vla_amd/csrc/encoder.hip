@@ -2099,6 +2099,8 @@ struct DeviceInfo {       // per device: a second HyperVLA on another GPU of the
 DeviceInfo g_dev[64];
 }  // namespace
 
+// every launch of an encoder call is counted (Profiler::nlaunch; hvla_launches): bench.py reports launches per step from here
+#define HVLA_LAUNCH(...) do { ++pf.nlaunch; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 template <typename Op>
 static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorkspace& ws, const uint8_t* images,
                               float* tokens, int B, hipStream_t st, Profiler* prof, bool keep_cls, uint32_t* audit) {
@@ -2211,10 +2213,10 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
         // (a three-stage form, three workgroups per CU for the launches above 512 blocks, was tried: run-to-run different
         // tokens in ~4 % of the episodes of a 1024-episode batch, whichever order the reads and the DMA issue are in, while
         // the four- and six-stage forms are clean -- not understood, not used: profiles/r3_experiments_not_kept.txt)
-        if (nblocks > ncu) hipLaunchKernelGGL((gemm64_kernel<Op, EPI, 4>), dim3(nblocks), dim3(256), 4 * 16384, st, c);   // two workgroups per CU
-        else hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
+        if (nblocks > ncu) HVLA_LAUNCH((gemm64_kernel<Op, EPI, 4>), dim3(nblocks), dim3(256), 4 * 16384, st, c);   // two workgroups per CU
+        else HVLA_LAUNCH((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
       } else {
-        hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
+        HVLA_LAUNCH((gemm64_kernel<Op, EPI>), dim3(nblocks), dim3(256), SNS * 16384, st, c);
       }
       pf.end(CAT_COMP, st);
       const int nbn = (N + HBN_ - 1) / HBN_;
@@ -2227,11 +2229,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
           lnx_args(a, ln_s, ln_b, nbn);
           const bool nt = (size_t)M * N * sizeof(float) >= ((size_t)96 << 20);      // a big batch: the residual rows are read past L2 (below)
           if (lnx_persistent(B, nbn)) {
-            if (nt) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true, true, true>), dim3(ncu), dim3(512), lds, st, a);
-            else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true, true>), dim3(ncu), dim3(512), lds, st, a);
+            if (nt) HVLA_LAUNCH((gemm256p_kernel<Op, EPI, true, true, true>), dim3(ncu), dim3(512), lds, st, a);
+            else HVLA_LAUNCH((gemm256p_kernel<Op, EPI, true, true>), dim3(ncu), dim3(512), lds, st, a);
           } else {
-            if (nt) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false, true, true>), dim3(B * nbn), dim3(512), lds, st, a);
-            else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false, true>), dim3(B * nbn), dim3(512), lds, st, a);
+            if (nt) HVLA_LAUNCH((gemm256p_kernel<Op, EPI, false, true, true>), dim3(B * nbn), dim3(512), lds, st, a);
+            else HVLA_LAUNCH((gemm256p_kernel<Op, EPI, false, true>), dim3(B * nbn), dim3(512), lds, st, a);
           }
           pf.end(cat, st);
           ln_fused = true;
@@ -2242,15 +2244,15 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
 #ifndef HVLA_EXP_NOSTNT
         // a big batch: the 16-bit output goes past L2, the f32 residual rows are read past it (see the epilogue)
         if ((size_t)M * N * (EPI == EPI_RES ? sizeof(float) : sizeof(T)) >= ((size_t)96 << 20)) {
-          if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true, false, true>), dim3(ncu), dim3(512), lds, st, a);
-          else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false, false, true>), dim3(B * nbn), dim3(512), lds, st, a);
+          if ((B * nbn) % ncu == 0) HVLA_LAUNCH((gemm256p_kernel<Op, EPI, true, false, true>), dim3(ncu), dim3(512), lds, st, a);
+          else HVLA_LAUNCH((gemm256p_kernel<Op, EPI, false, false, true>), dim3(B * nbn), dim3(512), lds, st, a);
           pf.end(cat, st);
           return true;
         }
 #endif
       }
-      if ((B * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), lds, st, a);
-      else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), lds, st, a);
+      if ((B * nbn) % ncu == 0) HVLA_LAUNCH((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), lds, st, a);
+      else HVLA_LAUNCH((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), lds, st, a);
       pf.end(cat, st);
       return true;
     }
@@ -2265,34 +2267,34 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
           if (ln_partial) {                              // the LayerNorm in front left the mean rows to this launch
             a.ln_partial = ln_partial;
             ln_partial = nullptr;
-            hipLaunchKernelGGL((gemm64c_kernel<Op, EPI, true>), dim3(nb64), dim3(256), gemm64c_fold_lds(K), st, a);
+            HVLA_LAUNCH((gemm64c_kernel<Op, EPI, true>), dim3(nb64), dim3(256), gemm64c_fold_lds(K), st, a);
             pf.end(cat, st);
             return false;
           }
         }
         if constexpr (EPI == EPI_RES) {
           if (2 * nb64 <= ncu) {                     // less than half of the chip: 64 x 32 tiles on twice as many CUs
-            hipLaunchKernelGGL((gemm64c32_kernel<Op>), dim3(2 * nb64), dim3(256), SNS32 * SST32, st, a);
+            HVLA_LAUNCH((gemm64c32_kernel<Op>), dim3(2 * nb64), dim3(256), SNS32 * SST32, st, a);
             pf.end(cat, st);
             return false;
           }
         }
-        hipLaunchKernelGGL((gemm64c_kernel<Op, EPI>), dim3(nb64), dim3(256), SNSC * SSTC, st, a);
+        HVLA_LAUNCH((gemm64c_kernel<Op, EPI>), dim3(nb64), dim3(256), SNSC * SSTC, st, a);
         pf.end(cat, st);
         return false;
       }
     }
     if (comp) {                                        // the same gemm64_body<EPI_CORR> arithmetic as the fused launch above
       GemmArgs c{ws.abar, dW, 2 * B, N, K, bias, nullptr, ws.corr, P, S, 0, 1.f};
-      hipLaunchKernelGGL((gemm64_kernel<Op, EPI_CORR>), dim3(((2 * B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
+      HVLA_LAUNCH((gemm64_kernel<Op, EPI_CORR>), dim3(((2 * B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
       a.corr = ws.corr;
     }
     pf.end(CAT_COMP, st);
     pf.begin(cat, st);
     if (M <= G64_MAXM && fits32 && N % SBN == 0 && K % 64 == 0)
-      hipLaunchKernelGGL((gemm64_kernel<Op, EPI>), dim3(((M + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, a);
+      HVLA_LAUNCH((gemm64_kernel<Op, EPI>), dim3(((M + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, a);
     else
-      hipLaunchKernelGGL((gemm_kernel<Op, EPI>), dim3(((M + GBM - 1) / GBM) * (N / GBN)), dim3(256), gsm, st, a);
+      HVLA_LAUNCH((gemm_kernel<Op, EPI>), dim3(((M + GBM - 1) / GBM) * (N / GBN)), dim3(256), gsm, st, a);
     pf.end(cat, st);
     return false;
   };
@@ -2302,7 +2304,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   auto layernorm = [&](const float* sc, const float* bi, int Nnext, void* scratch, int scratch_cols) {   // norm1 / norm2 (+ the column sums of the output)
     const bool room = (size_t)LNG * E * sizeof(float) <= (size_t)S * scratch_cols * sizeof(T);
     float* partial = comp && room ? reinterpret_cast<float*>(scratch) : nullptr;
-    hipLaunchKernelGGL((layernorm_group_kernel<Op>), dim3(LNG, B), dim3(LNW * 64), (size_t)(P / 8) * E * sizeof(float), st, ws.x,
+    HVLA_LAUNCH((layernorm_group_kernel<Op>), dim3(LNG, B), dim3(LNW * 64), (size_t)(P / 8) * E * sizeof(float), st, ws.x,
                        reinterpret_cast<T*>(ws.h), sc, bi, partial, S, P, E);
     if (!partial) return;
     // (one launch with the image's last workgroup to arrive -- ticket by atomicAdd behind a __threadfence -- adding the
@@ -2315,21 +2317,22 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       return;
     }
 #endif
-    hipLaunchKernelGGL((layernorm_mean_kernel<Op>), dim3(2 * B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), P, E);
+    HVLA_LAUNCH((layernorm_mean_kernel<Op>), dim3(2 * B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), P, E);
   };
   auto colmean_of = [&](const void* act, int K) {      // mean row of a GEMM output whose epilogue did not write it (no image-aligned tiles)
     if (!comp) return;
-    hipLaunchKernelGGL((colmean_kernel<T>), dim3((K + 255) / 256, B), dim3(256), 0, st, reinterpret_cast<const T*>(act),
+    HVLA_LAUNCH((colmean_kernel<T>), dim3((K + 255) / 256, B), dim3(256), 0, st, reinterpret_cast<const T*>(act),
                        reinterpret_cast<T*>(ws.abar), S, P, K);
   };
   auto audit_of = [&](const void* buf, size_t n, int site) {      // site: 0 LayerNorm out, 1 q/k/v, 2 attention out, 3 GELU out
     if (!audit) return;
-    hipLaunchKernelGGL((absmax_kernel<T>), dim3(1024), dim3(256), 0, st, reinterpret_cast<const T*>(buf), n / 8, audit + 2 * site);
+    HVLA_LAUNCH((absmax_kernel<T>), dim3(1024), dim3(256), 0, st, reinterpret_cast<const T*>(buf), n / 8, audit + 2 * site);
   };
   // the images' arrival words of the fused LayerNorms: zero before the first launch of every call (a memset node when the call is captured)
   if (can_fuse_ln && P == HBM_ && M > G64_MAXM) {
     if ((e = hipMemsetAsync(ws.ln_cnt, 0, (size_t)((B * 4 + 15) / 16 * 16), st)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(ws.ln_part, 0, (size_t)B * ((E + HBN_ - 1) / HBN_) * 256 * 16, st)) != hipSuccess) return e;   // the entries' tags
+    pf.nlaunch += 2;
   }
   using EQ = std::integral_constant<int, EPI_QKV>;
   using EG = std::integral_constant<int, EPI_GELU>;
@@ -2340,7 +2343,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     const size_t total = (size_t)B * P * (Kp / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
+    HVLA_LAUNCH(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
                        g.image_size, g.patch, g.grid(), Kp, ws.x, w.pos, S, E);
     const int Mp = B * P;
     GemmArgs a{ws.g, w.w_patch, Mp, E, Kp, w.b_patch, w.pos, ws.x, P, S, 0, 1.f / 256.f};
@@ -2351,15 +2354,15 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       if (P == HBM_ && can_fuse_ln && g.enc_layers > 0) {   // a tile row is an image: norm1 of layer 0 inside the epilogue (the CLS rows are written above)
         a.hsplit = hsplit;
         lnx_args(a, w.layer[0].ln1_s, w.layer[0].ln1_b, nbn);
-        if (lnx_persistent(a.nbm, nbn)) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true, true>), dim3(ncu), dim3(512), 131072, st, a);
-        else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false, true>), dim3(a.nbm * nbn), dim3(512), 131072, st, a);
+        if (lnx_persistent(a.nbm, nbn)) HVLA_LAUNCH((gemm256p_kernel<Op, EPI_PATCH, true, true>), dim3(ncu), dim3(512), 131072, st, a);
+        else HVLA_LAUNCH((gemm256p_kernel<Op, EPI_PATCH, false, true>), dim3(a.nbm * nbn), dim3(512), 131072, st, a);
         ln_fused = true;
-      } else if ((a.nbm * nbn) % ncu == 0) hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, true>), dim3(ncu), dim3(512), 131072, st, a);
-      else hipLaunchKernelGGL((gemm256p_kernel<Op, EPI_PATCH, false>), dim3(a.nbm * nbn), dim3(512), 131072, st, a);
+      } else if ((a.nbm * nbn) % ncu == 0) HVLA_LAUNCH((gemm256p_kernel<Op, EPI_PATCH, true>), dim3(ncu), dim3(512), 131072, st, a);
+      else HVLA_LAUNCH((gemm256p_kernel<Op, EPI_PATCH, false>), dim3(a.nbm * nbn), dim3(512), 131072, st, a);
     } else if (Mp <= G64_MAXM && fits32 && E % SBN == 0) {
-      hipLaunchKernelGGL((gemm64_kernel<Op, EPI_PATCH>), dim3(((Mp + SBM - 1) / SBM) * (E / SBN)), dim3(256), SNS * 16384, st, a);
+      HVLA_LAUNCH((gemm64_kernel<Op, EPI_PATCH>), dim3(((Mp + SBM - 1) / SBM) * (E / SBN)), dim3(256), SNS * 16384, st, a);
     } else {
-      hipLaunchKernelGGL((gemm_kernel<Op, EPI_PATCH>), dim3(((Mp + GBM - 1) / GBM) * (E / GBN)), dim3(256), gsm, st, a);
+      HVLA_LAUNCH((gemm_kernel<Op, EPI_PATCH>), dim3(((Mp + GBM - 1) / GBM) * (E / GBN)), dim3(256), gsm, st, a);
     }
   }
   pf.end(0, st);
@@ -2378,11 +2381,11 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
     pf.begin(3, st);
     if (ws.amap)
-      hipLaunchKernelGGL((attention_kernel<Op, true>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes + (size_t)KT * 32 * sizeof(float), st,
+      HVLA_LAUNCH((attention_kernel<Op, true>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes + (size_t)KT * 32 * sizeof(float), st,
                          reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr,
                          ws.amap + (size_t)l * H * (S - 1), g.enc_layers * H * (S - 1));
     else
-      hipLaunchKernelGGL((attention_kernel<Op, false>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
+      HVLA_LAUNCH((attention_kernel<Op, false>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
                          reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr,
                          nullptr, 0);
     pf.end(3, st);
@@ -2402,13 +2405,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   }
   pf.begin(1, st);
   if (keep_cls)
-    hipLaunchKernelGGL((layernorm_kernel<Op, 2>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s, w.lnf_b, M, E, S);
+    HVLA_LAUNCH((layernorm_kernel<Op, 2>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s, w.lnf_b, M, E, S);
   else
-    hipLaunchKernelGGL((layernorm_kernel<Op, 1>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s, w.lnf_b, M, E, S);
+    HVLA_LAUNCH((layernorm_kernel<Op, 1>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s, w.lnf_b, M, E, S);
   pf.end(1, st);
   return hipGetLastError();
 }
 
+#undef HVLA_LAUNCH
 #ifdef HVLA_BENCH_HOOKS
 hipError_t debug_lnx_stats(unsigned long long* out, int reset) {   // out: host [8][256]
   hipError_t e = hipDeviceSynchronize();

@@ -72,6 +72,7 @@ struct Profiler {
   std::vector<hipEvent_t> start, stop;
   std::vector<int> cat;
   size_t used = 0;
+  uint64_t nlaunch = 0;               // kernel launches since the last hvla_launches() (counted in run_encoder / hvla_policy / hvla_ensemble)
   bool want(int c) const { return c >= 0 && (mode == 2 || (mode == 1 && c == 5)); }
   void begin(int c, hipStream_t st) {
     if (!want(c)) return;
@@ -139,5 +140,6 @@ hipError_t launch_loss(const float* actions, const float* logits, const float* t
 
 // ---------------------------------------------------------------- self test
 hipError_t launch_selftest(int* fail_flags, hipStream_t st);
+hipError_t run_box_probe(float* sink, unsigned long long* ticks, float out[3], hipStream_t st);   // selftest.hip: sustained clock / MFMA rate of this box
 
 }  // namespace hvla

@@ -22,7 +22,8 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_selftest", "hvla_profile", "hvla_profile_read", "hvla_loss",
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
            "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit", "hvla_train_accumulate", "hvla_train_bucket_ranges",
-           "hvla_train_wait_bucket", "hvla_set_attention_outputs", "hvla_train_profile", "hvla_train_profile_read"]
+           "hvla_train_wait_bucket", "hvla_set_attention_outputs", "hvla_train_profile", "hvla_train_profile_read",
+           "hvla_launches", "hvla_box_probe"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy",
               "small_row_gemms"]      # mean rows + the 2 B latency-bound rows per GEMM: CLS rows and weight-rounding compensation rows
 
@@ -92,6 +93,10 @@ def load_library():
     lib.hvla_release_pooled_arenas.restype = C.c_int
     lib.hvla_weights_batch.argtypes = [vp]
     lib.hvla_weights_batch.restype = i32
+    lib.hvla_launches.argtypes = [vp]
+    lib.hvla_launches.restype = i64
+    lib.hvla_box_probe.argtypes = [vp, C.POINTER(C.c_float), vp]
+    lib.hvla_box_probe.restype = C.c_int
     lib.hvla_weights_export.argtypes = [vp, vp, vp, vp, vp]
     lib.hvla_weights_export.restype = C.c_int
     lib.hvla_encode.argtypes = [vp, vp, vp, i32, vp]
@@ -254,6 +259,16 @@ class Context:
         n = (C.c_int32 * len(PROF_NAMES))()
         self._check(self.lib.hvla_profile_read(self.h, ms, n), "hvla_profile_read")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(PROF_NAMES)}
+
+    def launches(self) -> int:
+        """Kernel launches (and memset nodes) enqueued by this ctx since the last call."""
+        return int(self.lib.hvla_launches(self.h))
+
+    def box_probe(self, stream=0):
+        """(sustained shader clock MHz under a chip-wide MFMA loop, that loop's TFLOP/s, its duration in ms)."""
+        out = (C.c_float * 3)()
+        self._check(self.lib.hvla_box_probe(self.h, out, C.c_void_p(stream)), "hvla_box_probe")
+        return float(out[0]), float(out[1]), float(out[2])
 
     # raw pointer-level calls (device pointers as ints)
     def generate(self, tok_ptr, mask_ptr, cls_ptr, B, stream=0):

@@ -278,6 +278,15 @@ int hvla_t5_encode(hvla_ctx* ctx, const int64_t* input_ids, const int64_t* atten
 int hvla_profile(hvla_ctx* ctx, int32_t mode);
 int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches);
 
+/* Measurement only (bench.py).  hvla_launches: kernel launches (and memset nodes) the ctx has enqueued since the last call
+ * -- hvla_encode / hvla_policy / hvla_step / hvla_ensemble count themselves -- so that "launches per step" is what the library
+ * did, not a restatement of its host logic.  hvla_box_probe: what THIS device sustains right now, in a probe kernel of its own
+ * (never inside a product kernel): out[0] = shader clock in MHz under a chip-wide matrix-core loop (shader-clock ticks per tick of
+ * the constant 100 MHz clock), out[1] = that loop's TFLOP/s (dense fp16 v_mfma_f32_32x32x16, eight waves per CU), out[2] = its
+ * duration in ms.  The boxes of a pool differ by several per cent: a step time is read against these.                        */
+int64_t hvla_launches(hvla_ctx* ctx);
+int hvla_box_probe(hvla_ctx* ctx, float out[3], void* stream);
+
 /* Test instrumentation: hvla_encode with a range audit of every 16-bit MFMA operand the encoder writes, over all layers:
  * site 0 LayerNorm outputs, 1 stored q / k / v, 2 attention outputs, 3 GELU outputs.  maxabs f32 [4] = largest finite
  * |value| per site, nonfinite i32 [4] = number of inf / NaN values (an fp16 overflow shows up here).  HOST pointers.    */
