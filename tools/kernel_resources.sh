@@ -16,4 +16,9 @@ for e in md.split('  - .agpr_count:')[1:]:
     g = lambda k: re.search(r'\.' + k + r':\s+(\d+)', e).group(1)
     print(f"{dem[:100]:100s} vgpr {g('vgpr_count'):>3} sgpr {g('sgpr_count'):>3} spill {g('vgpr_spill_count'):>3} scratch {g('private_segment_fixed_size'):>4} lds {g('group_segment_fixed_size')}")
 PY
+# the policy kernel's tile hand-over must contain the written-out fence (__syncthreads() emits no vmcnt wait on gfx950)
+if [ "$SRC" = policy ]; then
+  n=$(grep -c "s_waitcnt vmcnt(0) lgkmcnt(0)" *gfx950.s || true)
+  echo "policy.hip: $n x 's_waitcnt vmcnt(0) lgkmcnt(0)' in the ISA (the tile fence of acquire(): must be > 0)"
+fi
 echo "(asm in $D)"

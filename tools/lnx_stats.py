@@ -40,3 +40,5 @@ for name, row in (("whole epilogue", 1), ("[A] x into registers", 5), ("[B] stat
 print(f"  tiles abandoned {a[3].sum():.0f}, normalised from memory by the last arriver {a[4].sum():.0f}")
 w = a[2] / n
 print("  wait by workgroup id (first 40):", np.round(w[:40]).astype(int).tolist())
+slow = a[4]
+print("  tiles normalised from memory, by workgroup id (nonzero):", {int(i): int(v) for i, v in enumerate(slow) if v})
