@@ -230,6 +230,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2: hvla_step runs the two halves of the batch on two streams (more actions/s; per-kernel "
                          "durations then include time shared with the other half, so the roofline line is not comparable)")
+    ap.add_argument("--latency-samples", type=int, default=0,
+                    help="per-step latency samples for p50 (default: >= 100; the profiler passes of tools/collect_profiles.sh ask for fewer)")
     ap.add_argument("--ensemble", action="store_true",
                     help="include the device-side un-normalise + temporal ensemble in every step (always on with --graph)")
     ap.add_argument("--finetune", action="store_true",
@@ -344,6 +346,8 @@ def main():
     # p50 over >= 200 samples for a replayed graph (config 3) and for the small batches whose metric IS the latency (B <= 8),
     # over >= 100 at the headline batch (30 for the 60-120 ms steps of 1024 / 2048 episodes)
     n_lat = max(a.steps, 200) if (a.graph or B <= 8) else max(a.steps, 100 if B <= 512 else 30)
+    if a.latency_samples > 0:
+        n_lat = a.latency_samples
     for _ in range(n_lat):
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
