@@ -1936,6 +1936,64 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       }
   }
   HVLA_ASTAMP();                                           // 5 normalised, column sums, stores issued
+#ifndef HVLA_EXP_LASTQ_VALU
+  // ---- the last query, through the matrix pipe (round 5).  Its scores against key tile `wave` are one 32 x 32 tile of S^T = K Q^T
+  // whose 32 columns are all THIS query (the B fragment is the parked query, the same in every lane column), so every lane holds
+  // the 16 keys of its half in registers: max / sum are in-lane + one exchange between the halves, P feeds the P.V tile from
+  // registers exactly as in pass 2, and the partial (max, sum, O[64]) goes to LDS from one lane column.  On the VALU (rounds 1-4:
+  // 32 fma per key with converts, a 32-step readlane loop for P.V) this was 9 400 of an item's 34 000 clock ticks in a kernel whose
+  // two workgroups per CU contend for VALU issue (profiles/r5_experiments_not_kept.txt 5).  The last wave also takes the final key
+  // tile (one real key, the rest masked).
+  {
+    X8 ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ql[ks] = *reinterpret_cast<const X8*>(qxs + ks * 16 + half * 8);
+    auto lastq = [&](int tile, bool masked) {
+      f32x16 c = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) c = Op::mma32(kfrag(tile, ks), ql[ks], c);
+      if (masked) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = (tile * 32 + crow(r, half) < S) ? c[r] : -1e30f;
+      }
+      float m = c[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, c[r]);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      X8 pf[2];
+      f32x2v l2 = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2v p2 = {__builtin_amdgcn_exp2f(c[r] - m), __builtin_amdgcn_exp2f(c[r + 1] - m)};
+        l2 += p2;
+        pf[r >> 3][r & 7] = (T)p2[0];
+        pf[r >> 3][(r & 7) + 1] = (T)p2[1];
+      }
+      float l = l2[0] + l2[1];
+      l += __shfl_xor(l, 32, 64);
+      f32x16 ol[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        ol[mt] = zero16();
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+          const T* v0 = vtr + ((tile * 32 + sstep * 16) * AVLD) + ((mt * 32) ^ vsw);
+          ol[mt] = Op::mma32(tr_read2<X8>(v0, v0 + 8 * AVLD), pf[sstep], ol[mt]);
+        }
+      }
+      float* pp = part + tile * 66;
+      if (col == 0) {                      // one lane column: lane (0, half) holds d = 32 mt + crow(r, half)
+        if (half == 0) pp[0] = m, pp[1] = l;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pp[2 + 32 * mt + crow(r, half)] = ol[mt][r];
+      }
+    };
+    lastq(wave, false);
+    if (wave == NW - 1) lastq(KT - 1, true);
+  }
+#else
   // ---- the last query, VALU: wave w scores key tile w (lane = key, the two halves split d), the last wave also the
   // final key S-1; partial softmax + partial P.V (lane = d); combine across waves through LDS.
   {
@@ -1981,6 +2039,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       pp[2 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
     }
   }
+#endif
   __syncthreads();
   HVLA_ASTAMP();                                           // 6 last-query partials done
   if (wave == 0) {
