@@ -1585,6 +1585,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
           if (!((bits >> (16 + c)) & 1u) || c * HBN_ + wn_x * 64 >= gp->N) continue;       // (wave-uniform)
           const uint32_t ncol = (uint32_t)(c * HBN_ + wn_x * 64 + 4 * fr_x);
           const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gp->ln_scale + ncol), bt4 = *reinterpret_cast<const f32x4*>(gp->ln_bias + ncol);
+#ifdef HVLA_EXP_MEMSERIAL                                    // (A/B: all 32 rows in, then the sweep -- two serial passes per tile)
           const uint32_t vo = ((uint32_t)(im * gp->S + 1 + wm_x * 128 + 4 * fq_x) * (uint32_t)gp->N + ncol) * 4u;
           int rowb = gp->N * 4;
           asm volatile("" : "+s"(rowb));
@@ -1594,6 +1595,57 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
             for (int r = 0; r < 4; ++r)
               xk[mt][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)vo, (16 * mt + r) * rowb, 0));
           sweep(im, c, gm4, bt4);
+#else
+          // the rows stream through a ring of three m-tiles (as in [A]): the loads of m-tile mt + 2 are in flight while m-tile mt is
+          // normalised and stored -- this route runs on ONE CU at the end of a launch, and as "all rows in, then the sweep" it was two
+          // exposed memory latencies per tile.  The arithmetic and the order of the column sums are sweep()'s.
+          {
+            const uint32_t vox = ((uint32_t)(im * gp->S + 1 + wm_x * 128 + 4 * fq_x) * (uint32_t)gp->N + ncol) * 4u;
+            const uint32_t voh = ((uint32_t)(im * gp->S + 1 + wm_x * 128 + 4 * fq_x) * (uint32_t)gp->N + ncol) * (uint32_t)sizeof(T);
+            int rowbx = gp->N * 4, rowbh = gp->N * (int)sizeof(T);
+            asm volatile("" : "+s"(rowbx), "+s"(rowbh));
+            f32x4 ring[3][4];
+            auto req = [&](int mt) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                ring[mt % 3][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)vox, (16 * mt + r) * rowbx, 0));
+            };
+            req(0);
+            req(1);
+            f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+              if (mt + 2 < 8) req(mt + 2);
+              const lds_f4* mp = (const lds_f4*)(mr + (wm_x * 128 + 16 * mt + 4 * fq_x) * 2);
+              const f32x4 m01 = mp[0], m23 = mp[1];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float mean = r < 2 ? m01[2 * r] : m23[2 * r - 4], rstd = r < 2 ? m01[2 * r + 1] : m23[2 * r - 3];
+                const f32x4 xv = ring[mt % 3][r];
+                typename Op::x4 o;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                  const float y = ln_value(xv[cc], mean, rstd, gm4[cc], bt4[cc]);
+                  cs[cc] = (mt == 0 && r == 0) ? y : cs[cc] + y;                 // ascending rows
+                  o[cc] = (T)y;
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), hrs, (int)voh, (16 * mt + r) * rowbh, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (gp->ln_abar) {
+              typename Op::x4 mo;
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc) {
+                float t = cs[cc];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);                                      // (p0 + p1) + (p2 + p3)
+                mo[cc] = (T)(t * (1.f / 128.f));
+              }
+              if (fq_x == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_abar) + ((size_t)im * 2 + wm_x) * gp->N + ncol) = mo;
+            }
+          }
+#endif
 #ifdef HVLA_BENCH_HOOKS
           ++dbg_slow;
 #endif
