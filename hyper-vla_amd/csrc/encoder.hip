@@ -234,6 +234,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
         else t[c] = acc[c][mp + u] + b4[c];
         if constexpr (EPI == EPI_QKV) t[c] *= q;
         if constexpr (EPI == EPI_GELU) {
+          // (the same chain on plain instead of packed fmas -- a packed f32 instruction costs attention_kernel three plain ones --
+          // changes nothing here: fc1 3.81 / 3.76 against 3.81 / 3.80 ms per step, same box; two waves per SIMD, stores in between)
           const f32x2 g0 = gelu_erf2(f32x2{t[c][0], t[c][1]}), g1 = gelu_erf2(f32x2{t[c][2], t[c][3]});
           t[c] = f32x4{g0[0], g0[1], g1[0], g1[1]};
         }
@@ -1797,7 +1799,9 @@ __device__ __forceinline__ X8 tr_read2(const void* p0, const void* p1) {
 
 // omean (nullable): [B][E] 16-bit mean over all S tokens of the image of the output, the operand of the out-projection's
 // weight-rounding compensation (the corr rows of gemm64_kernel): the workgroup owns every row of its 64 columns.
-template <typename Op, bool AMAP = false>      // AMAP: the opt-in instantiation that also exports the CLS query's attention row
+// NWC: the number of 32-query waves as a compile-time constant (8 at S = 257: the key-tile loops unroll, their LDS addresses become
+// immediate offsets), 0 = taken from S at run time (the small test geometries).
+template <typename Op, bool AMAP = false, int NWC = 0>      // AMAP: the opt-in instantiation that also exports the CLS query's attention row
 __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, typename Op::elem* __restrict__ o,
                                  int S, int E, int H, typename Op::elem* __restrict__ omean,
                                  float* __restrict__ amap     // nullable: this layer's slice [B][..][H][S - 1] of the CLS query's attention over the patch keys
@@ -1821,7 +1825,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   using T = typename Op::elem;
   using X8 = typename Op::x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int NW = (S - 1) / 32, KT = NW + 1, SP = KT * 32;
+  const int NW = NWC ? NWC : (S - 1) / 32, KT = NW + 1, SP = KT * 32;
   T* Ks = reinterpret_cast<T*>(smem);                      // [SP][64]  keys, 16-B chunks XOR-swizzled by key & 7
   T* Vs = Ks + SP * AVLD;                                  // [SP][64]  values, row-major (read transposed)
   T* qxs = Vs + SP * AVLD;                                 // [64]       the last query (parked here, not in registers)
@@ -1848,6 +1852,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   // K first, then V: V is only needed in the second pass, so its loads stay in flight (in registers) under the first.
   constexpr int STG = 8;
   X8 kreg[STG], vreg[STG];
+#ifdef HVLA_EXP_STAGE_FLAT
 #pragma unroll
   for (int it = 0; it < STG; ++it) {
     if (it * nthr >= SP * 8) break;                        // uniform
@@ -1882,6 +1887,62 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     }
     __syncthreads();
   };
+
+#else
+  // Round 5: the kernel is bound by instruction issue (four waves per SIMD, ~2 500 instructions per wave and item), and a fifth
+  // of them were this staging: per chunk a 64-bit address, a zero fill, two compares and a branch.  Now one 32-bit offset per
+  // thread into a buffer resource that ends with the image's last row: chunk `it` is 64 keys further on (a scalar offset), K
+  // and V are E and 2 E elements behind q (scalar too), the padding keys are out of the resource's range and come back as
+  // zeros, and the LDS addresses of a thread's chunks differ by constants.  (The range check of a raw buffer on gfx9 does not
+  // see the scalar offset, so the padding chunks get their out-of-range offset in the VGPR.)
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)((size_t)S * rowstride * sizeof(T)) - head * 128, 0x00020000);
+  const int key0 = tid >> 3;
+  const uint32_t kvo = (uint32_t)key0 * (uint32_t)(rowstride * sizeof(T)) + (tid & 7) * 16;
+  const int kround = nthr >> 3;                                                     // keys per round of chunks
+  const uint32_t kstep = (uint32_t)kround * (uint32_t)(rowstride * sizeof(T));      // (scalar) bytes between a thread's chunks
+  auto chunk_vo = [&](int it) -> int { return key0 < S - it * kround ? (int)kvo : 0x7fff0000; };   // chunk `it` of this thread: key key0 + it * kround
+#pragma unroll
+  for (int it = 0; it < STG; ++it) {
+    if (it * nthr >= SP * 8) break;                        // uniform
+    // (K and V are read exactly once per step: non-temporal loads, 1.88 -> 1.84 ms per step)
+    kreg[it] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(krs, chunk_vo(it), (int)(it * kstep) + E * (int)sizeof(T), 2));        // aux 2 = nt
+  }
+#pragma unroll
+  for (int it = 0; it < STG; ++it) {
+    if (it * nthr >= SP * 8) break;
+    vreg[it] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(krs, chunk_vo(it), (int)(it * kstep) + 2 * E * (int)sizeof(T), 2));
+  }
+  // LDS side: chunk `it` lies kround rows behind chunk it - 1 in both images when kround is a multiple of 16 (kperm() exchanges
+  // bits 0 and 3 of the key, the swizzles use bits 0-2); one workgroup wave (the tiny test geometries) takes the general form.
+  const int ch0 = tid & 7;
+  T* const kdst = Ks + kperm(key0) * AVLD + ((ch0 ^ (key0 & 7)) * 8);
+  T* const vdst = Vs + key0 * AVLD + ((ch0 ^ (((key0 >> 1) & 1) << 2)) * 8);
+  const bool klin = (kround & 15) == 0;                    // uniform
+  if (klin) {
+#pragma unroll
+    for (int it = 0; it < STG; ++it) {
+      if (it * nthr >= SP * 8) break;
+      if (key0 + it * kround < SP) *reinterpret_cast<X8*>(kdst + it * kround * AVLD) = kreg[it];
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < STG; ++it) {
+      if (it * nthr >= SP * 8) break;
+      const int key = key0 + it * kround;
+      if (key < SP) *reinterpret_cast<X8*>(Ks + kperm(key) * AVLD + ((ch0 ^ (key & 7)) * 8)) = kreg[it];
+    }
+  }
+  __syncthreads();
+  HVLA_ASTAMP();                                           // 1 K staged
+  auto stage_v = [&] {
+#pragma unroll
+    for (int it = 0; it < STG; ++it) {
+      if (it * nthr >= SP * 8) break;
+      if (key0 + it * kround < SP) *reinterpret_cast<X8*>(vdst + it * kround * AVLD) = vreg[it];
+    }
+    __syncthreads();
+  };
+#endif
 
   // per-lane part of the transposed-read address: row (half * 4 + q), column 16 * dgrp + 4 p, and the 64-B
   // half swap of rows with bit 1 set (q >= 2)
@@ -1923,7 +1984,12 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
   };
-  for (int kt = 0; kt < KT - 1; ++kt) rowmax(qk(kt, zero16()));
+  if constexpr (NWC != 0) {
+#pragma unroll
+    for (int kt = 0; kt < NWC; ++kt) rowmax(qk(kt, zero16()));
+  } else {
+    for (int kt = 0; kt < KT - 1; ++kt) rowmax(qk(kt, zero16()));
+  }
   rowmax(qk(KT - 1, mask16()));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   HVLA_ASTAMP();                                           // 2 pass 1 done
@@ -1943,7 +2009,17 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         clsrow[kt * 32 + crow(r, half)] = p2[0];
         clsrow[kt * 32 + crow(r + 1, half)] = p2[1];
       }
+#ifdef HVLA_EXP_LSUM_PACKED
       lsum2 += p2;
+#else
+      // two plain adds, kept apart by the asm statements: as ONE v_pk_add_f32 (what `lsum2 += p2` compiles to, and what the
+      // compiler makes of two adjacent adds by itself) the kernel is 3.5 % SLOWER with 72 instructions fewer -- a packed f32
+      // instruction costs this issue-bound kernel about three plain ones (same box: attention 1.572 -> 1.517 ms per step)
+      { float la = lsum2[0], lb = lsum2[1];
+        la += p2[0]; asm volatile("" : "+v"(la));
+        lb += p2[1]; asm volatile("" : "+v"(lb));
+        lsum2[0] = la, lsum2[1] = lb; }
+#endif
       pf[r >> 3][r & 7] = (T)p2[0];
       pf[r >> 3][(r & 7) + 1] = (T)p2[1];
     }
@@ -1957,7 +2033,14 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       }
     }
   };
-  for (int kt = 0; kt < KT - 1; ++kt) pv(kt, qk(kt, zero16()));
+  // (-max as the accumulator input of a tile's first MFMA -- ONE tuple of 16 registers for all key tiles, no subtraction per
+  // element -- does not fit: 128 VGPRs + spills, and the tuple is copied per tile.)
+  if constexpr (NWC != 0) {
+#pragma unroll
+    for (int kt = 0; kt < NWC; ++kt) pv(kt, qk(kt, zero16()));
+  } else {
+    for (int kt = 0; kt < KT - 1; ++kt) pv(kt, qk(kt, zero16()));
+  }
   pv(KT - 1, qk(KT - 1, mask16()));
   const float lsum = lsum2[0] + lsum2[1];
   const float inv = 1.f / (lsum + __shfl_xor(lsum, 32, 64));
@@ -1969,6 +2052,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   }
   {
     T* op = o + ((size_t)b * S + q) * E + head * 64;
+#ifdef HVLA_EXP_CSUM_ROWS
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1986,6 +2070,55 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         }
         *reinterpret_cast<typename Op::x4*>(op + mt * 32 + g4 * 8 + half * 4) = v4;
       }
+#else
+    // The lane's 32 outputs (item j = 16 mt + 4 g4 + r: column d = 32 mt + 8 g4 + 4 half + r) are to be summed over the 32 lanes
+    // (queries) of its half.  Round 5: a reduce-scatter over the lane bits instead of 32 full 32-lane reductions (each 4 DPP
+    // adds + a ds_bpermute + a masked LDS store: a fifth of an item's clock ticks in a kernel that is bound by VALU issue).
+    // Lane bit 4 (the two 16-lane rows of a half): v_permlane16_swap exchanges the odd rows of the mt = 0 value with the even rows
+    // of the mt = 1 value, one add leaves item j in the even row and item j + 16 in the odd one; bits 3 .. 0: the lanes whose
+    // bit is clear keep the lower half of the remaining items, the others the upper half, and add the partner's share (row
+    // mirror, half-row mirror and the two quad permutations: each pairs lanes that differ in that bit).  Lane l ends with the
+    // sum of item l & 31: 77 instructions and one LDS store.  (The order of the additions differs from rounds 1-4; these mean
+    // rows only feed the weight-rounding compensation, to per cents.)
+    // (The instruction is issued by hand: hipcc 7.2 returns the FIRST result of __builtin_amdgcn_permlane16_swap in both elements
+    // of its pair -- tools/permlane_swap_probe.hip.  `s_nop 1`: two wait states between a VALU write and the swap that reads it,
+    // which the hazard recognizer cannot place inside an asm statement.)
+    float w16[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) O[0][j] *= inv, O[1][j] *= inv;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        typename Op::x4 v4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = (T)O[mt][g4 * 4 + r];
+        *reinterpret_cast<typename Op::x4*>(op + mt * 32 + g4 * 8 + half * 4) = v4;
+      }
+    if (omean) {
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        float a0 = O[0][j], a1 = O[0][j + 1], a2 = O[0][j + 2], a3 = O[0][j + 3];
+        float b0 = O[1][j], b1 = O[1][j + 1], b2 = O[1][j + 2], b3 = O[1][j + 3];
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        w16[j] = a0 + b0, w16[j + 1] = a1 + b1, w16[j + 2] = a2 + b2, w16[j + 3] = a3 + b3;
+      }
+    }
+    if (omean) {
+      const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+      float w8[8], w4[4], w2[2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w8[j] = (b3 ? w16[j + 8] : w16[j]) + dpp_mov<0x140>(b3 ? w16[j] : w16[j + 8]);     // row_mirror
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w4[j] = (b2 ? w8[j + 4] : w8[j]) + dpp_mov<0x141>(b2 ? w8[j] : w8[j + 4]);         // row_half_mirror
+#pragma unroll
+      for (int j = 0; j < 2; ++j) w2[j] = (b1 ? w4[j + 2] : w4[j]) + dpp_mov<0x4E>(b1 ? w4[j] : w4[j + 2]);          // lanes ^ 2
+      const float w1 = (b0 ? w2[1] : w2[0]) + dpp_mov<0xB1>(b0 ? w2[0] : w2[1]);                                     // lanes ^ 1
+      const int j = lane & 31;                                                                                       // = 16 mt + 4 g4 + r
+      csum[wave * 64 + (j >> 4) * 32 + ((j >> 2) & 3) * 8 + half * 4 + (j & 3)] = w1;
+    }
+#endif
   }
   HVLA_ASTAMP();                                           // 5 normalised, column sums, stores issued
 #ifndef HVLA_EXP_LASTQ_VALU
@@ -2043,7 +2176,20 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       }
     };
     lastq(wave, false);
+#ifdef HVLA_EXP_LASTKEY_MFMA
     if (wave == NW - 1) lastq(KT - 1, true);
+#else
+    // The final key tile holds ONE real key (token S - 1): p = 1, sum = 1, P.V = its V row, the score one 64-term dot product
+    // (lane = d) -- a dozen VALU instructions on the first wave instead of a second masked 32-key tile on the last one, which
+    // every other wave then waited for at the barrier below.
+    if (wave == 0) {
+      const int key = S - 1;
+      const float sc = wave64_sum((float)qxs[lane] * (float)Ks[kperm(key) * AVLD + (((lane >> 3) ^ (key & 7)) * 8) + (lane & 7)]);
+      float* pp = part + (KT - 1) * 66;
+      if (lane == 0) pp[0] = sc, pp[1] = 1.f;
+      pp[2 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
+    }
+#endif
   }
 #else
   // ---- the last query, VALU: wave w scores key tile w (lane = key, the two halves split d), the last wave also the
@@ -2095,21 +2241,55 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   __syncthreads();
   HVLA_ASTAMP();                                           // 6 last-query partials done
   if (wave == 0) {
-    float M = -1e30f;
-    for (int t = 0; t < KT; ++t) M = fmaxf(M, part[t * 66]);
-    float L = 0.f, od = 0.f;
-    for (int t = 0; t < KT; ++t) {
-      const float f = __builtin_amdgcn_exp2f(part[t * 66] - M);
-      L = fmaf(part[t * 66 + 1], f, L);
-      od = fmaf(part[t * 66 + 2 + lane], f, od);
+    // (every value is requested before the first is used: KT and NW are run-time numbers, and a rolled loop pays an LDS round
+    // trip per partial while the workgroup's other waves have already left)
+    constexpr int KTM = 9;
+    float last;
+    if (KT <= KTM) {
+      float pm[KTM], pl[KTM], po[KTM];
+#pragma unroll
+      for (int t = 0; t < KTM; ++t) {
+        const bool in = t < KT;
+        pm[t] = in ? part[t * 66] : -1e30f;
+        pl[t] = in ? part[t * 66 + 1] : 0.f;
+        po[t] = in ? part[t * 66 + 2 + lane] : 0.f;
+      }
+      float M = -1e30f;
+#pragma unroll
+      for (int t = 0; t < KTM; ++t) M = fmaxf(M, pm[t]);
+      float L = 0.f, od = 0.f;
+#pragma unroll
+      for (int t = 0; t < KTM; ++t) {
+        const float f = __builtin_amdgcn_exp2f(pm[t] - M);
+        L = fmaf(pl[t], f, L);
+        od = fmaf(po[t], f, od);
+      }
+      last = od / L;
+    } else {
+      float M = -1e30f;
+      for (int t = 0; t < KT; ++t) M = fmaxf(M, part[t * 66]);
+      float L = 0.f, od = 0.f;
+      for (int t = 0; t < KT; ++t) {
+        const float f = __builtin_amdgcn_exp2f(part[t * 66] - M);
+        L = fmaf(part[t * 66 + 1], f, L);
+        od = fmaf(part[t * 66 + 2 + lane], f, od);
+      }
+      last = od / L;
     }
-    const float last = od / L;
     o[((size_t)b * S + (S - 1)) * E + head * 64 + lane] = (T)last;
     if (omean) {               // [image][half][E]: tokens [0, 32 NW / 2) and the rest (the wave split; half a wave's width off the
       const int NH = NW / 2;   // consumer's token split for odd NW, one token off at S = 257: the mean only needs per cents)
       float t0 = 0.f, t1 = last;
-      for (int w = 0; w < NH; ++w) t0 += csum[w * 64 + lane];
-      for (int w = NH; w < NW; ++w) t1 += csum[w * 64 + lane];
+      if (NW == 8) {
+        float c[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) c[w] = csum[w * 64 + lane];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t0 += c[w], t1 += c[4 + w];
+      } else {
+        for (int w = 0; w < NH; ++w) t0 += csum[w * 64 + lane];
+        for (int w = NH; w < NW; ++w) t1 += csum[w * 64 + lane];
+      }
       if (NH == 0) t0 = t1;                                  // one wave (tiny geometries): both rows carry the whole image's mean
       omean[((size_t)b * 2 + 0) * E + head * 64 + lane] = (T)(t0 / (float)(NH ? NH * 32 : S));
       omean[((size_t)b * 2 + 1) * E + head * 64 + lane] = (T)(t1 / (float)(NH ? S - NH * 32 : S));
@@ -2234,7 +2414,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
 #define SETA(K) \
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     SETA((gemm_kernel<Op, EPI_PATCH>)) SETA((gemm_kernel<Op, EPI_QKV>)) SETA((gemm_kernel<Op, EPI_GELU>))
-    SETA((gemm_kernel<Op, EPI_RES>)) SETA((attention_kernel<Op, false>)) SETA((attention_kernel<Op, true>))
+    SETA((gemm_kernel<Op, EPI_RES>)) SETA((attention_kernel<Op, false>)) SETA((attention_kernel<Op, true>)) SETA((attention_kernel<Op, false, 8>))
     SETA((gemm256p_kernel<Op, EPI_PATCH, false>)) SETA((gemm256p_kernel<Op, EPI_QKV, false>))
     SETA((gemm256p_kernel<Op, EPI_GELU, false>)) SETA((gemm256p_kernel<Op, EPI_RES, false>))
     SETA((gemm256p_kernel<Op, EPI_PATCH, true>)) SETA((gemm256p_kernel<Op, EPI_QKV, true>))
@@ -2491,14 +2671,25 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     gemm(EQ{}, ws.h, L.wqkv, L.dqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, 2);                       // the LayerNorm wrote the mean row itself
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
     pf.begin(3, st);
-    if (ws.amap)
-      HVLA_LAUNCH((attention_kernel<Op, true>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes + (size_t)KT * 32 * sizeof(float), st,
-                         reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr,
-                         ws.amap + (size_t)l * H * (S - 1), g.enc_layers * H * (S - 1));
-    else
-      HVLA_LAUNCH((attention_kernel<Op, false>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st,
-                         reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H, comp ? reinterpret_cast<T*>(ws.abar) : nullptr,
-                         nullptr, 0);
+#ifdef HVLA_EXP_ATT_ROLLED
+    constexpr bool att_unrolled = false;
+#else
+    const bool att_unrolled = KT == 9;
+#endif
+    auto attn = [&](auto kern, size_t lds) {
+      HVLA_LAUNCH(kern, dim3(B * H), dim3((KT - 1) * 64), lds, st, reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H,
+                  comp ? reinterpret_cast<T*>(ws.abar) : nullptr, ws.amap ? ws.amap + (size_t)l * H * (S - 1) : nullptr, g.enc_layers * H * (S - 1)
+#ifdef HVLA_BENCH_HOOKS
+                  , (unsigned long long*)nullptr, 0     // (default arguments do not travel through a function pointer)
+#endif
+                  );
+    };
+    if (ws.amap) {                     // (unrolled, the attention-map instantiation spills: it stays rolled)
+      attn(attention_kernel<Op, true>, asm_bytes + (size_t)KT * 32 * sizeof(float));
+    } else {
+      if (att_unrolled) attn(attention_kernel<Op, false, 8>, asm_bytes);
+      else attn(attention_kernel<Op, false>, asm_bytes);
+    }
     pf.end(3, st);
     audit_of(ws.h, (size_t)M * E, 2);
     gemm(ER{}, ws.h, L.wo, L.dwo, E, E, L.bo, L.ls1, ws.x, 0, 4, nullptr, L.ln2_s, L.ln2_b);   // the attention kernel wrote the mean row itself; norm2 as the tail
@@ -2590,9 +2781,17 @@ hipError_t debug_attention_stamps(const void* qkv, void* o, void* omean, int B, 
   const int KT = (S + 31) / 32;
   const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * 66 * sizeof(float) + 64 * sizeof(T) +
                            (size_t)(KT - 1) * 64 * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<Op, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((attention_kernel<Op, false>), dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st, reinterpret_cast<const T*>(qkv),
-                     reinterpret_cast<T*>(o), S, E, H, reinterpret_cast<T*>(omean), nullptr, 0, stamps, wg);
+  auto go = [&](auto kern) {           // the instantiation the step launches at this S (run_encoder)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st, reinterpret_cast<const T*>(qkv),
+                       reinterpret_cast<T*>(o), S, E, H, reinterpret_cast<T*>(omean), (float*)nullptr, 0, stamps, wg);
+  };
+#ifdef HVLA_EXP_ATT_ROLLED
+  go(attention_kernel<Op, false>);
+#else
+  if (KT == 9) go(attention_kernel<Op, false, 8>);
+  else go(attention_kernel<Op, false>);
+#endif
   return hipGetLastError();
 }
 #endif  // HVLA_BENCH_HOOKS
