@@ -1831,7 +1831,8 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   T* qxs = Vs + SP * AVLD;                                 // [64]       the last query (parked here, not in registers)
   float* part = reinterpret_cast<float*>(qxs + 64);        // [KT][66]   partial (max, sum, O[64]) of the last query
   float* csum = part + KT * 66;                            // [NW][64]   per-wave column sums of the output
-  float* clsrow = csum + NW * 64;                          // [SP]       AMAP only: the CLS query's unnormalised probabilities (a region of
+  float* clsm = csum + NW * 64;                            // [32]       AMAP only: the running maximum every key tile's entries of clsrow are relative to
+  float* clsrow = clsm + 32;                               // [SP]       AMAP only: the CLS query's unnormalised probabilities (a region of
                                                            // its own: `part` is written by the other waves' tails while wave 0 may still be in pass 2)
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthr = blockDim.x;
@@ -1852,43 +1853,6 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   // K first, then V: V is only needed in the second pass, so its loads stay in flight (in registers) under the first.
   constexpr int STG = 8;
   X8 kreg[STG], vreg[STG];
-#ifdef HVLA_EXP_STAGE_FLAT
-#pragma unroll
-  for (int it = 0; it < STG; ++it) {
-    if (it * nthr >= SP * 8) break;                        // uniform
-    const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) kreg[it][j] = (T)0.f;
-    // (K and V are read exactly once per step: non-temporal loads, 1.88 -> 1.84 ms per step)
-    if (i < SP * 8 && key < S) kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const X8*>(base + (size_t)key * rowstride + E + ch * 8));
-  }
-#pragma unroll
-  for (int it = 0; it < STG; ++it) {
-    if (it * nthr >= SP * 8) break;
-    const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) vreg[it][j] = (T)0.f;
-    if (i < SP * 8 && key < S) vreg[it] = __builtin_nontemporal_load(reinterpret_cast<const X8*>(base + (size_t)key * rowstride + 2 * E + ch * 8));
-  }
-#pragma unroll
-  for (int it = 0; it < STG; ++it) {
-    if (it * nthr >= SP * 8) break;
-    const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
-    if (i < SP * 8) *reinterpret_cast<X8*>(Ks + kperm(key) * AVLD + ((ch ^ (key & 7)) * 8)) = kreg[it];
-  }
-  __syncthreads();
-  HVLA_ASTAMP();                                           // 1 K staged
-  auto stage_v = [&] {
-#pragma unroll
-    for (int it = 0; it < STG; ++it) {
-      if (it * nthr >= SP * 8) break;
-      const int i = tid + it * nthr, key = i >> 3, ch = i & 7;
-      if (i < SP * 8) *reinterpret_cast<X8*>(Vs + key * AVLD + ((ch ^ (((key >> 1) & 1) << 2)) * 8)) = vreg[it];
-    }
-    __syncthreads();
-  };
-
-#else
   // Round 5: the kernel is bound by instruction issue (four waves per SIMD, ~2 500 instructions per wave and item), and a fifth
   // of them were this staging: per chunk a 64-bit address, a zero fill, two compares and a branch.  Now one 32-bit offset per
   // thread into a buffer resource that ends with the image's last row: chunk `it` is 64 keys further on (a scalar offset), K
@@ -1932,8 +1896,10 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       if (key < SP) *reinterpret_cast<X8*>(Ks + kperm(key) * AVLD + ((ch0 ^ (key & 7)) * 8)) = kreg[it];
     }
   }
+#ifdef HVLA_EXP_TWOPASS
   __syncthreads();
-  HVLA_ASTAMP();                                           // 1 K staged
+#endif
+  HVLA_ASTAMP();                                           // 1 K staged (one pass: V follows, one barrier for both)
   auto stage_v = [&] {
 #pragma unroll
     for (int it = 0; it < STG; ++it) {
@@ -1942,7 +1908,6 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     }
     __syncthreads();
   };
-#endif
 
   // per-lane part of the transposed-read address: row (half * 4 + q), column 16 * dgrp + 4 p, and the 64-B
   // half swap of rows with bit 1 set (q >= 2)
@@ -1980,6 +1945,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     return z;
   };
   float mx = -1e30f;
+#ifdef HVLA_EXP_TWOPASS
   auto rowmax = [&](const f32x16& sc) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
@@ -1995,13 +1961,51 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   HVLA_ASTAMP();                                           // 2 pass 1 done
   stage_v();
   HVLA_ASTAMP();                                           // 3 V staged
+#else
+  HVLA_ASTAMP();                                           // 2 (no first pass)
+  stage_v();
+  HVLA_ASTAMP();                                           // 3 V staged
+#endif
   typedef float f32x2v __attribute__((ext_vector_type(2)));
   f32x2v lsum2 = {0.f, 0.f};        // this half's partial denominator (two interleaved partial sums)
   f32x16 O[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) O[0][r] = 0.f, O[1][r] = 0.f;
+  // ONE pass over the keys (round 5; rounds 1-4 ran K Q^T twice: row maxima first, then exp2 against the final maximum).  The
+  // maximum runs along, and O / the denominator are rescaled LAZILY: only when some query of the wave meets a tile whose maximum
+  // lies more than 8 (a factor 256 -- p stays below 2^8, far inside the 16-bit formats' range) above the maximum it is using, which
+  // after the first tile or two does not happen -- a wave-uniform branch that is not taken.  Against the second K Q^T that is
+  // 36 MFMAs, 36 ds_read_b128 (a third of the kernel's LDS bytes) and ~90 VALU instructions less per wave and item; a tile's
+  // maximum costs eight v_max3 and one exchange between the two halves of the query's lanes (v_permlane32_swap, by hand: see
+  // the column sums below).  Deterministic and batch-invariant as before: the branch depends on the (image, head)'s data only.
+  auto tile_max = [&](const f32x16& sc) {
+    float t = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) t = fmaxf(t, sc[r]);
+    float u = t;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(u));     // t = [lower half's, lower half's], u = [upper, upper]
+    // rounded up to an integer: maxima then differ by whole numbers, every rescale factor (and the factor between the p of two
+    // rescale policies) is an exact power of two, and o does not depend on when which maximum was in use
+    return __builtin_ceilf(fmaxf(t, u));
+  };
   auto pv = [&](int kt, const f32x16& sc) {
     X8 pf[2];
+#ifndef HVLA_EXP_TWOPASS
+    {
+      const float tm = tile_max(sc);
+      if (kt == 0) {
+        mx = tm;
+      } else if (__builtin_amdgcn_ballot_w64(tm > mx + 8.f) != 0) {
+        const float mn = fmaxf(mx, tm);
+        const float al = __builtin_amdgcn_exp2f(mx - mn);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[0][r] *= al, O[1][r] *= al;
+        lsum2[0] *= al, lsum2[1] *= al;
+        mx = mn;
+      }
+      if (AMAP && wave == 0 && lane == 0) clsm[kt] = mx;   // the maximum this tile's row of the attention map is relative to
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       const f32x2v p2 = {__builtin_amdgcn_exp2f(sc[r] - mx), __builtin_amdgcn_exp2f(sc[r + 1] - mx)};
@@ -2048,7 +2052,12 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   if (AMAP && wave == 0) {       // outputs.attentions[layer][b, head, 0, 1:] (base_vit.py:117-118, hypervla_interface.py:210-211)
     const float i0 = lane_bcast(inv, 0);
     float* am = amap + (size_t)b * amap_stride + (size_t)head * (S - 1);
+#ifdef HVLA_EXP_TWOPASS
     for (int j = lane; j < S - 1; j += 64) am[j] = clsrow[1 + j] * i0;
+#else
+    const float m0 = lane_bcast(mx, 0);
+    for (int j = lane; j < S - 1; j += 64) am[j] = clsrow[1 + j] * __builtin_amdgcn_exp2f(clsm[(1 + j) >> 5] - m0) * i0;
+#endif
   }
   {
     T* op = o + ((size_t)b * S + q) * E + head * 64;
@@ -2685,7 +2694,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
                   );
     };
     if (ws.amap) {                     // (unrolled, the attention-map instantiation spills: it stays rolled)
-      attn(attention_kernel<Op, true>, asm_bytes + (size_t)KT * 32 * sizeof(float));
+      attn(attention_kernel<Op, true>, asm_bytes + (size_t)(KT * 32 + 32) * sizeof(float));
     } else {
       if (att_unrolled) attn(attention_kernel<Op, false, 8>, asm_bytes);
       else attn(attention_kernel<Op, false>, asm_bytes);
