@@ -1777,6 +1777,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // Attention, head_dim 64.  qkv [B*S][3E] 16-bit (q already scaled by log2(e)/sqrt(64)); out o [B*S][E].
 constexpr int AKLD = 72;          // K row stride in LDS (halves): 144 B
+constexpr int APS = 68;           // floats per partial of the last query: max, sum, 2 unused, O[64] (16-byte aligned)
 constexpr int AVLD = 64;          // V row stride (halves): 128 B, 64-B halves swapped on rows with bit 1 set
 // K rows are 128 B = half of the 64 banks, so a row's bank half is its row parity, and the 16-B chunk swizzle (chunk ^ key & 7)
 // alone leaves every ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: guide, LDS table) with two keys
@@ -1829,8 +1830,8 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   T* Ks = reinterpret_cast<T*>(smem);                      // [SP][64]  keys, 16-B chunks XOR-swizzled by key & 7
   T* Vs = Ks + SP * AVLD;                                  // [SP][64]  values, row-major (read transposed)
   T* qxs = Vs + SP * AVLD;                                 // [64]       the last query (parked here, not in registers)
-  float* part = reinterpret_cast<float*>(qxs + 64);        // [KT][66]   partial (max, sum, O[64]) of the last query
-  float* csum = part + KT * 66;                            // [NW][64]   per-wave column sums of the output
+  float* part = reinterpret_cast<float*>(qxs + 64);        // [KT][APS]  partial (max, sum, -, -, O[64]) of the last query
+  float* csum = part + KT * APS;                            // [NW][64]   per-wave column sums of the output
   float* clsm = csum + NW * 64;                            // [32]       AMAP only: the running maximum every key tile's entries of clsrow are relative to
   float* clsrow = clsm + 32;                               // [SP]       AMAP only: the CLS query's unnormalised probabilities (a region of
                                                            // its own: `part` is written by the other waves' tails while wave 0 may still be in pass 2)
@@ -1978,6 +1979,18 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   // 36 MFMAs, 36 ds_read_b128 (a third of the kernel's LDS bytes) and ~90 VALU instructions less per wave and item; a tile's
   // maximum costs eight v_max3 and one exchange between the two halves of the query's lanes (v_permlane32_swap, by hand: see
   // the column sums below).  Deterministic and batch-invariant as before: the branch depends on the (image, head)'s data only.
+  // a value of the two halves of a query's lanes combined, the same in both (v_permlane32_swap on the value and a copy of it
+  // leaves [lower, lower] in one register and [upper, upper] in the other; a ds_bpermute round trip otherwise)
+  auto half_exchange_max = [](float t) {
+    float u = t;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(u));
+    return fmaxf(t, u);
+  };
+  auto half_exchange_sum = [](float t) {
+    float u = t;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(u));
+    return t + u;
+  };
   auto tile_max = [&](const f32x16& sc) {
     float t = sc[0];
 #pragma unroll
@@ -2037,8 +2050,9 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       }
     }
   };
-  // (-max as the accumulator input of a tile's first MFMA -- ONE tuple of 16 registers for all key tiles, no subtraction per
-  // element -- does not fit: 128 VGPRs + spills, and the tuple is copied per tile.)
+  // (The scores relative to the maximum in use -- -max as the accumulator input of a tile's first MFMA, one tuple of 16 registers
+  // rewritten only when the maximum moves, p = exp2(score) with no subtraction: 16 instructions less per key tile -- was built: 1 %.
+  // After the one-pass form this kernel is no longer bound by its VALU instruction count.)
   if constexpr (NWC != 0) {
 #pragma unroll
     for (int kt = 0; kt < NWC; ++kt) pv(kt, qk(kt, zero16()));
@@ -2046,8 +2060,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     for (int kt = 0; kt < KT - 1; ++kt) pv(kt, qk(kt, zero16()));
   }
   pv(KT - 1, qk(KT - 1, mask16()));
-  const float lsum = lsum2[0] + lsum2[1];
-  const float inv = 1.f / (lsum + __shfl_xor(lsum, 32, 64));
+  const float inv = 1.f / half_exchange_sum(lsum2[0] + lsum2[1]);
   HVLA_ASTAMP();                                           // 4 pass 2 done
   if (AMAP && wave == 0) {       // outputs.attentions[layer][b, head, 0, 1:] (base_vit.py:117-118, hypervla_interface.py:210-211)
     const float i0 = lane_bcast(inv, 0);
@@ -2153,18 +2166,19 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       float m = c[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, c[r]);
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = half_exchange_max(m);
       X8 pf[2];
-      f32x2v l2 = {0.f, 0.f};
+      float la = 0.f, lb = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const f32x2v p2 = {__builtin_amdgcn_exp2f(c[r] - m), __builtin_amdgcn_exp2f(c[r + 1] - m)};
-        l2 += p2;
-        pf[r >> 3][r & 7] = (T)p2[0];
-        pf[r >> 3][(r & 7) + 1] = (T)p2[1];
+        const float p0 = __builtin_amdgcn_exp2f(c[r] - m), p1 = __builtin_amdgcn_exp2f(c[r + 1] - m);
+        la += p0; asm volatile("" : "+v"(la));       // (plain adds: see pass 2)
+        lb += p1; asm volatile("" : "+v"(lb));
+        pf[r >> 3][r & 7] = (T)p0;
+        pf[r >> 3][(r & 7) + 1] = (T)p1;
       }
-      float l = l2[0] + l2[1];
-      l += __shfl_xor(l, 32, 64);
+      float l = la + lb;
+      l = half_exchange_sum(l);
       f32x16 ol[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -2175,13 +2189,14 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
           ol[mt] = Op::mma32(tr_read2<X8>(v0, v0 + 8 * AVLD), pf[sstep], ol[mt]);
         }
       }
-      float* pp = part + tile * 66;
-      if (col == 0) {                      // one lane column: lane (0, half) holds d = 32 mt + crow(r, half)
+      float* pp = part + tile * APS;
+      if (col == 0) {                      // one lane column: lane (0, half) holds d = 32 mt + crow(r, half) = 32 mt + 8 (r >> 2) + 4 half + (r & 3)
         if (half == 0) pp[0] = m, pp[1] = l;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) pp[2 + 32 * mt + crow(r, half)] = ol[mt][r];
+          for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<f32x4*>(pp + 4 + 32 * mt + 8 * g4 + 4 * half) = f32x4{ol[mt][4 * g4], ol[mt][4 * g4 + 1], ol[mt][4 * g4 + 2], ol[mt][4 * g4 + 3]};
       }
     };
     lastq(wave, false);
@@ -2194,9 +2209,9 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     if (wave == 0) {
       const int key = S - 1;
       const float sc = wave64_sum((float)qxs[lane] * (float)Ks[kperm(key) * AVLD + (((lane >> 3) ^ (key & 7)) * 8) + (lane & 7)]);
-      float* pp = part + (KT - 1) * 66;
+      float* pp = part + (KT - 1) * APS;
       if (lane == 0) pp[0] = sc, pp[1] = 1.f;
-      pp[2 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
+      pp[4 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
     }
 #endif
   }
@@ -2234,16 +2249,16 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         const int k2 = tile * 32 + i;
         od = fmaf(lane_bcast(p, i), (float)Vs[k2 * AVLD + (lane ^ (((k2 >> 1) & 1) << 5))], od);
       }
-      float* pp = part + tile * 66;
+      float* pp = part + tile * APS;
       if (lane == 0) pp[0] = m, pp[1] = l;
-      pp[2 + lane] = od;
+      pp[4 + lane] = od;
     }
     if (wave == NW - 1) {                // the one real key of tile KT-1 (= S-1): p = 1, sum = 1, P.V = its V row
       const int key = S - 1;
       const float sc = score(key);
-      float* pp = part + (KT - 1) * 66;
+      float* pp = part + (KT - 1) * APS;
       if (lane == 0) pp[0] = sc, pp[1] = 1.f;
-      pp[2 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
+      pp[4 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
     }
   }
 #endif
@@ -2259,9 +2274,9 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 #pragma unroll
       for (int t = 0; t < KTM; ++t) {
         const bool in = t < KT;
-        pm[t] = in ? part[t * 66] : -1e30f;
-        pl[t] = in ? part[t * 66 + 1] : 0.f;
-        po[t] = in ? part[t * 66 + 2 + lane] : 0.f;
+        pm[t] = in ? part[t * APS] : -1e30f;
+        pl[t] = in ? part[t * APS + 1] : 0.f;
+        po[t] = in ? part[t * APS + 4 + lane] : 0.f;
       }
       float M = -1e30f;
 #pragma unroll
@@ -2276,12 +2291,12 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       last = od / L;
     } else {
       float M = -1e30f;
-      for (int t = 0; t < KT; ++t) M = fmaxf(M, part[t * 66]);
+      for (int t = 0; t < KT; ++t) M = fmaxf(M, part[t * APS]);
       float L = 0.f, od = 0.f;
       for (int t = 0; t < KT; ++t) {
-        const float f = __builtin_amdgcn_exp2f(part[t * 66] - M);
-        L = fmaf(part[t * 66 + 1], f, L);
-        od = fmaf(part[t * 66 + 2 + lane], f, od);
+        const float f = __builtin_amdgcn_exp2f(part[t * APS] - M);
+        L = fmaf(part[t * APS + 1], f, L);
+        od = fmaf(part[t * APS + 4 + lane], f, od);
       }
       last = od / L;
     }
@@ -2667,7 +2682,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   }
   pf.end(0, st);
   const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
-  const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * 66 * sizeof(float) + 64 * sizeof(T) +
+  const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * APS * sizeof(float) + 64 * sizeof(T) +
                            (size_t)(KT - 1) * 64 * sizeof(float);
   for (int l = 0; l < g.enc_layers; ++l) {
     const EncLayerW& L = w.layer[l];
@@ -2788,7 +2803,7 @@ hipError_t debug_attention_stamps(const void* qkv, void* o, void* omean, int B, 
   using Op = OpF16;
   using T = Op::elem;
   const int KT = (S + 31) / 32;
-  const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * 66 * sizeof(float) + 64 * sizeof(T) +
+  const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * APS * sizeof(float) + 64 * sizeof(T) +
                            (size_t)(KT - 1) * 64 * sizeof(float);
   auto go = [&](auto kern) {           // the instantiation the step launches at this S (run_encoder)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
