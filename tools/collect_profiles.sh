@@ -43,6 +43,8 @@ timeout 300 python tools/lnx_stats.py 256 > $P/${RND}_lnx_stats.txt 2>/dev/null
 timeout 300 python tools/lnx_check.py 800 8 9 40 64 85 86 255 256 512 > $P/${RND}_lnx_same_bytes.txt 2>/dev/null
 timeout 300 python tools/lnx_check.py 0 8 64 256 512 >> $P/${RND}_lnx_same_bytes.txt 2>/dev/null
 timeout 300 python tools/attention_timeline.py 256 > $P/${RND}_attention_timeline.txt 2>/dev/null
+{ timeout 300 python tools/attention_omean_check.py 16 2>/dev/null | tail -5
+  hipcc --offload-arch=gfx950 -O3 tools/permlane_swap_probe.hip -o /tmp/psp 2>/dev/null && timeout 60 /tmp/psp; } > $P/${RND}_attention_mean_rows_and_swap_probe.txt 2>&1
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -s -m gpu -k "sixty_four or full_geometry_against_golden" 2>/dev/null | grep -E "npz|passed|failed" > $P/${RND}_accuracy.txt
 { hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/policy_hazard_probe.hip -o /tmp/php 2>/dev/null && timeout 300 /tmp/php 1500
   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_war_probe.hip -o /tmp/mwp 2>/dev/null && timeout 120 /tmp/mwp
