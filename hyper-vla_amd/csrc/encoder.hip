@@ -915,15 +915,22 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_group_kernel(const float* 
     b4[i] = col < n4 ? reinterpret_cast<const f32x4*>(bias)[col] : z;
   }
   const int nwork = nrows + (grp == 0 ? 1 : 0);                      // index nrows (group 0 only) = the CLS row
-  for (int i = wave; i < nwork; i += LNW) {                          // wave-uniform
+  auto row_in = [&](int i, f32x4 (&r)[4]) {
     const int tok = i < nrows ? tok0 + 16 * (i >> 2) + (i & 3) : 0;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((size_t)b * S + tok) * E);
-    f32x4 cur[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int col = lane + 64 * c;
-      cur[c] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
+      r[c] = col < n4 ? xr[col] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  // the wave's next row is requested before this one is worked on (at B = 1 a launch is two rows per wave and nothing else on
+  // the chip: the second row's memory round trip used to start after the first row's stores)
+  f32x4 cur[4], nxt[4];
+  if (wave < nwork) row_in(wave, cur);
+  for (int i = wave; i < nwork; i += LNW) {                          // wave-uniform
+    const int tok = i < nrows ? tok0 + 16 * (i >> 2) + (i & 3) : 0;
+    if (i + LNW < nwork) row_in(i + LNW, nxt);
     float mean, rstd;
     ln_row_stats<4>(cur, invE, mean, rstd);
     typename Op::elem* orow = out + ((size_t)b * S + tok) * E;
@@ -942,12 +949,22 @@ __global__ __launch_bounds__(LNW * 64) void layernorm_group_kernel(const float* 
         if (partial && i < nrows) ys[i * n4 + col] = y;
       }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
   }
   if (!partial) return;
   __syncthreads();
   if ((int)threadIdx.x < n4) {
     f32x4 cs = ys[threadIdx.x];
-    for (int i = 1; i < nrows; ++i) cs += ys[i * n4 + threadIdx.x];
+    int i = 1;
+    for (; i + 8 <= nrows; i += 8) {                                   // eight LDS reads in flight, added in index order
+      f32x4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = ys[(i + j) * n4 + threadIdx.x];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cs += t[j];
+    }
+    for (; i < nrows; ++i) cs += ys[i * n4 + threadIdx.x];
     reinterpret_cast<f32x4*>(partial + ((size_t)b * LNG + grp) * E)[threadIdx.x] = cs;
   }
 }
