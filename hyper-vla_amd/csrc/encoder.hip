@@ -49,8 +49,8 @@ __global__ void im2col_kernel(const uint8_t* __restrict__ img, typename Op::elem
                               int image, int patch, int grid, int Kp, float* __restrict__ x, const float* __restrict__ pos, int S, int E) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * E; i += (size_t)gridDim.x * blockDim.x)
     x[(i / E) * S * E + (i % E)] = pos[i % E];
-  // one thread = 8 consecutive k of one patch row
-  const int chunks = Kp / 8, Kp1 = Kp / 2;
+  // one thread = 8 consecutive k of one patch row, converted once and stored into both halves of the row (Kp1 is a multiple of 8)
+  const int Kp1 = Kp / 2, chunks = Kp1 / 8;
   const size_t total = (size_t)B * grid * grid * chunks;
   const int kreal = patch * patch * 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -62,8 +62,7 @@ __global__ void im2col_kernel(const uint8_t* __restrict__ img, typename Op::elem
     // (dy, byte in row) of the chunk's first element and the other seven follow by compare / subtract
     typename Op::x8 v;
     const int rowb = 3 * patch;
-    int k0 = ch * 8;
-    k0 = k0 >= Kp1 ? k0 - Kp1 : k0;                  // Kp1 is a multiple of 8: a chunk never straddles the two halves
+    const int k0 = ch * 8;
     int dy = k0 / rowb, rb = k0 - dy * rowb;
     const uint8_t* src = img + ((b * image + (size_t)(py * patch + dy)) * image + (size_t)px * patch) * 3;
 #pragma unroll
@@ -74,6 +73,7 @@ __global__ void im2col_kernel(const uint8_t* __restrict__ img, typename Op::elem
       if (++rb == rowb) rb = 0, src += (size_t)image * 3;
     }
     *reinterpret_cast<typename Op::x8*>(out + m * Kp + ch * 8) = v;
+    *reinterpret_cast<typename Op::x8*>(out + m * Kp + Kp1 + ch * 8) = v;
   }
 }
 
@@ -2672,7 +2672,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   // patch embedding
   pf.begin(0, st);
   {
-    const size_t total = (size_t)B * P * (Kp / 8);
+    const size_t total = (size_t)B * P * (Kp / 16);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     HVLA_LAUNCH(im2col_kernel<Op>, dim3(blocks), dim3(256), 0, st, images, reinterpret_cast<T*>(ws.g), B,
