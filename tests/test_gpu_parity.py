@@ -371,6 +371,42 @@ def test_hf_torch_dinov2_state_dict_through_the_encoder(tmp_path):
     assert hid.shape == (3, 257, 768) and np.sqrt((d * d).mean()) <= 1e-3 and np.abs(d).max() <= 1e-2, (np.sqrt((d * d).mean()), np.abs(d).max())
 
 
+def test_attention_with_maxima_that_grow_along_the_keys():
+    """attention_kernel makes ONE pass over the keys: the row maximum runs along (rounded up to an integer) and O / the denominator
+    are rescaled lazily, only when a key tile's maximum lies more than 8 (log2 units) above the maximum in use.  Synthetic weights
+    give flat rows (the branch is taken for the first tile only); here the query / key projections of a one-layer DINOv2-base
+    are scaled up until rows are peaked and thousands of (query, tile) pairs take the rescale -- counted on the float64 oracle's
+    scores -- and the hidden states are compared with the oracle (FlaxDinov2SelfAttention via base_vit.py:117)."""
+    _need_gpu()
+    from hypervla import synthetic as syn
+    from hypervla.config import encoder_leaves, Geometry
+    from hypervla.model import HyperVLA
+    from oracle import hvla_ref_np as onp
+    g = Geometry(enc_layers=1)
+    params = dict(syn.synthetic_params(g))
+    pre = "encoder_image_encoder_encoder_layer_0_attention_attention_"
+    for nm in ("query", "key"):
+        params[pre + nm + "_kernel"] = np.asarray(params[pre + nm + "_kernel"]) * 6.0
+    m = HyperVLA.from_synthetic(g, params=params, max_batch=4)
+    im = syn.synthetic_images_structured(3, g)
+    hid = m.encode_initial_image(im).cpu().numpy().astype(np.float64)
+    sink = {}
+    ref = onp.dinov2(m.params, g, dict(encoder_leaves(g)), onp.normalize_images(im[:, 0]), sink=sink)
+    s2 = sink["enc/scores0"] * np.log2(np.e)                            # [B, H, S, S] in the kernel's log2 domain
+    S = s2.shape[-1]
+    tiles = [np.ceil(s2[..., t:t + 32].max(-1)) for t in range(0, S, 32)]
+    run, rescales = tiles[0].copy(), 0
+    for t in tiles[1:]:
+        hit = t > run + 8
+        rescales += int(hit.sum())
+        run = np.where(hit, np.maximum(run, t), run)
+    d = hid - ref
+    print("peaked attention: score range %.1f log2 units, %d (query, tile) rescales, hidden rms %.2e max %.2e"
+          % (s2.max() - s2.min(), rescales, np.sqrt((d * d).mean()), np.abs(d).max()))
+    assert rescales > 1000
+    assert np.sqrt((d * d).mean()) <= 2e-3 and np.abs(d).max() <= 3e-2, (np.sqrt((d * d).mean()), np.abs(d).max())
+
+
 def test_attention_maps_against_the_oracle(full):
     """The two attention slices `InferenceWrapper(save_attention_map=True)` keeps (data/utils/hypervla_interface.py:208-217):
     DINOv2's CLS-query attention over the patches [B, 12, 12, 256] and the generated policy's action-token attention over
