@@ -405,6 +405,20 @@ def test_attention_with_maxima_that_grow_along_the_keys():
           % (s2.max() - s2.min(), rescales, np.sqrt((d * d).mean()), np.abs(d).max()))
     assert rescales > 1000
     assert np.sqrt((d * d).mean()) <= 2e-3 and np.abs(d).max() <= 3e-2, (np.sqrt((d * d).mean()), np.abs(d).max())
+    # the CLS query's exported row: its entries are stored relative to the maximum in use at their key tile and brought to the final
+    # maximum at the end (the attention-map instantiation of the kernel)
+    from hypervla.config import generated_leaves
+    B = 2
+    ins, st = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g)
+    w, tasks, _ = m.create_tasks(instruction_dict=ins, initial_state=st)
+    act0, _ = m.sample_actions(im[:B], ins, tasks, np.ones((B, 1)), w)
+    act, inter = m.sample_actions(im[:B], ins, tasks, np.ones((B, 1)), w, attention_maps=True)
+    assert np.array_equal(act, act0)
+    bp, _ = onp.create_tasks(m.params, g, generated_leaves(g), ins, st)
+    dino, _ = onp.attention_maps(m.params, g, dict(encoder_leaves(g)), bp, im[:B])
+    dd = np.abs(inter["dino_cls_attention"] - dino)
+    print("peaked attention: CLS row max |d| %.2e (max weight %.2e)" % (dd.max(), dino.max()))
+    assert inter["dino_cls_attention"].shape == dino.shape and dd.max() <= 2e-2 * max(dino.max(), 0.05)
 
 
 def test_attention_maps_against_the_oracle(full):
