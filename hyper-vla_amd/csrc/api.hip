@@ -51,6 +51,7 @@ struct hvla_ctx {
   int device = 0;
   std::string err;
   bool loaded = false;
+  bool train_timer = false;      // this context switched its device's GEMM timer on (hvla_train_profile): hvla_destroy gives the events back
   PackedLayout lay;
   int Kp = 0;
   // device weights
@@ -183,6 +184,7 @@ int hvla_create(const hvla_config* c, int device, hvla_ctx** out) {
 void hvla_destroy(hvla_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->train_timer) train_gemm_timer_release();
   delete ctx;
 }
 
@@ -711,7 +713,9 @@ int hvla_train_wait_bucket(hvla_ctx* ctx, int32_t bucket, void* stream) {
 
 int hvla_train_profile(hvla_ctx* ctx, int32_t on) {
   if (!ctx) return HVLA_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   train_gemm_timer(on != 0);
+  if (on) ctx->train_timer = true;
   return HVLA_OK;
 }
 

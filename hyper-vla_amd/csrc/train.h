@@ -27,7 +27,8 @@ struct BG {
   long sBias1 = 0;            // bias stride of the inner batch index b1
 };
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0);
-void train_gemm_timer(bool on);                                                  // hvla_train_profile
+void train_gemm_timer(bool on);                                                  // hvla_train_profile (the current device's timer)
+void train_gemm_timer_release();                                                 // hvla_destroy: the current device's events
 hipError_t train_gemm_timer_read(float* ms, double* flops, int* launches);      // since the last read
 
 // flat layout of the trainable hypernetwork parameters (float32 elements)

@@ -358,19 +358,42 @@ static constexpr bool train_gemm_exact() { return false; }
 
 // Optional live timing of the batched GEMM launches (hvla_train_profile: bench.py --finetune's `roofline` block): HIP events on
 // the launch stream around every bgemm() call and the f32-equivalent work of the call (2 M N K per batch entry; the split-bf16
-// kernel spends three matrix instructions per product).  Off by default; not thread-safe (one training stream per process).
+// kernel spends three matrix instructions per product).  Off by default.  One timer per DEVICE (a context belongs to one device and
+// the API entry points make it current before they launch; ADVICE r4: a process-wide timer mixed the contexts of two devices and
+// never gave its events back): events are created on that device, destroyed by train_gemm_timer_release() from hvla_destroy, and a
+// launch into a stream that is being captured is not timed (events recorded inside a capture cannot be read).  Not thread-safe
+// (one training stream per device).
 namespace {
 struct GemmTimer {
   bool on = false;
   std::vector<hipEvent_t> a, b;
   size_t used = 0;
   double flops = 0.0;
-} g_gemm_timer;
+};
+GemmTimer g_gemm_timer[64];
+GemmTimer* gemm_timer_here() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return &g_gemm_timer[dev];
+}
 }  // namespace
-void train_gemm_timer(bool on) { g_gemm_timer.on = on; }
+void train_gemm_timer(bool on) {
+  if (GemmTimer* t = gemm_timer_here()) t->on = on;
+}
+void train_gemm_timer_release() {
+  GemmTimer* t = gemm_timer_here();
+  if (!t) return;
+  for (hipEvent_t e : t->a) (void)hipEventDestroy(e);
+  for (hipEvent_t e : t->b) (void)hipEventDestroy(e);
+  t->a.clear(), t->b.clear();
+  t->used = 0, t->flops = 0.0, t->on = false;
+}
 hipError_t train_gemm_timer_read(float* ms, double* flops, int* launches) {
-  GemmTimer& t = g_gemm_timer;
-  *ms = 0.f; *flops = t.flops; *launches = (int)t.used;
+  *ms = 0.f; *flops = 0.0; *launches = 0;
+  GemmTimer* tp = gemm_timer_here();
+  if (!tp) return hipErrorInvalidDevice;
+  GemmTimer& t = *tp;
+  *flops = t.flops; *launches = (int)t.used;
   for (size_t i = 0; i < t.used; ++i) {
     hipError_t e = hipEventSynchronize(t.b[i]);
     if (e != hipSuccess) return e;
@@ -383,11 +406,14 @@ hipError_t train_gemm_timer_read(float* ms, double* flops, int* launches) {
 }
 static void bgemm_launch(hipStream_t st, bool ta, bool tb, BG g, int nb0);
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
-  GemmTimer& t = g_gemm_timer;
-  if (!t.on) { bgemm_launch(st, ta, tb, g, nb0); return; }
+  GemmTimer* tp = gemm_timer_here();
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (!tp || !tp->on || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { bgemm_launch(st, ta, tb, g, nb0); return; }
+  GemmTimer& t = *tp;
   if (t.used == t.a.size()) {
     hipEvent_t x, y;
-    if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) { bgemm_launch(st, ta, tb, g, nb0); return; }
+    if (hipEventCreate(&x) != hipSuccess) { bgemm_launch(st, ta, tb, g, nb0); return; }
+    if (hipEventCreate(&y) != hipSuccess) { (void)hipEventDestroy(x); bgemm_launch(st, ta, tb, g, nb0); return; }
     t.a.push_back(x), t.b.push_back(y);
   }
   (void)hipEventRecord(t.a[t.used], st);

@@ -146,7 +146,7 @@ class HyperVLA:
                 if model.audit_operand_range() is None:
                     warnings.warn("operand-range audit skipped: the checkpoint has no example batch with image_primary frames; "
                                   "call model.audit_operand_range(images) on real observations", RuntimeWarning)
-            except ValueError as e:
+            except Exception as e:              # (also a failure of the example frames' resize: under 'warn' it must not block the load)
                 if audit == "raise":
                     raise
                 warnings.warn(f"{e} (audit='warn': loaded anyway)", RuntimeWarning)
@@ -166,13 +166,14 @@ class HyperVLA:
                 images = np.asarray(self.example_batch["observation"]["image_primary"])
             except (TypeError, KeyError):
                 return None
+        images = np.asarray(images)[: self.max_batch]      # (sliced first: an example batch of many large frames is neither moved nor resized in full)
         img = self._dev(images, torch.uint8)
         if img.dim() == 5:
             img = img[:, 0].contiguous()
         g = self.geometry
         if tuple(img.shape[1:]) != (g.image_size, g.image_size, 3):
             img = self.preprocess_images(img)  # example frames of another size: the evaluators' resize (InferenceWrapper._resize_image)
-        img = img[: self.max_batch].contiguous()
+        img = img.contiguous()
         audit = self._ctx.encode_audit(img.data_ptr(), img.shape[0], self._stream())      # {site: (max |x|, non-finite count)}
         sites = {k: v[0] for k, v in audit.items()}
         bad = {k: v[1] for k, v in audit.items() if v[1]}
