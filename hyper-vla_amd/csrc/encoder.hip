@@ -833,6 +833,21 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x141>(v);
   return v + dpp_mov<0x140>(v);
 }
+// v + (the value of lane ^ 16) / v + (the value of lane ^ 32), without a lane id and without the LDS crossbar: v_permlane16_swap /
+// v_permlane32_swap on the value and a copy of it leave [row 0, row 0, row 2, row 2] | [row 1, row 1, row 3, row 3] (lower half twice |
+// upper half twice) in the two registers.  Same bits as v + __shfl_xor(v, 16 / 32) (an addition commutes).  Issued by hand: hipcc 7.2's
+// builtin returns its first result twice (tools/permlane_swap_probe.hip); `s_nop 1`: two wait states behind the VALU write of v.
+// (__shfl_xor needs __lane_id(), which the compiler computes once in front of a persistent kernel's tile loop and keeps -- or spills.)
+__device__ __forceinline__ float xor16_sum(float v) {
+  float u = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(u));
+  return v + u;
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float u = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(u));
+  return v + u;
+}
 __device__ __forceinline__ float lane_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
@@ -1341,19 +1356,26 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         }
         const float q = gp->qscale;
         const float vmask = wvalid ? 1.f : 0.f;
-        f32x4 xin[3][4];                                 // a ring of three m-tiles
+        // (a ring of four: same step within the noise of two same-box runs -- out 1.665 / 1.740 against 1.680 / 1.697 ms -- once the spill
+        // it caused was gone; five spills 16-23 registers in the persistent form.  The phase is not limited by the bytes in flight.)
+#if defined(HVLA_EXP_XRING4)
+        constexpr int XR = 4;
+#else
+        constexpr int XR = 3;
+#endif
+        f32x4 xin[XR][4];                                // a ring of XR m-tiles
         int rowb = gp->N * 4;                              // bytes per row; opaque at every site that forms the 32 scalar row offsets: shared, the
         asm volatile("" : "+s"(rowb));                   // compiler keeps all of them in SGPRs through the epilogue and spills a hundred others
         auto request = [&](int mt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            xin[mt % 3][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)ivo, (16 * mt + r) * rowb, (EPI == EPI_RES && NTOUT) ? 2 : 0));   // aux 2 = nt
+            xin[mt % XR][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)ivo, (16 * mt + r) * rowb, (EPI == EPI_RES && NTOUT) ? 2 : 0));   // aux 2 = nt
         };
-        request(0);
-        request(1);
+#pragma unroll
+        for (int mt = 0; mt < XR - 1; ++mt) request(mt);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
-          if (mt + 2 < 8) request(mt + 2);
+          if (mt + XR - 1 < 8) request(mt + XR - 1);
           f32x4 t[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -1362,7 +1384,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            f32x4 x = xin[mt % 3][r];
+            f32x4 x = xin[mt % XR][r];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               if constexpr (EPI == EPI_RES) x[c] = fmaf(t[c][r], pl4[c], x[c]);
@@ -1566,8 +1588,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             float t = cs[c];
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);                                        // (p0 + p1) + (p2 + p3)
+            t = xor32_sum(xor16_sum(t));                                       // (p0 + p1) + (p2 + p3)
             mo[c] = (T)(t * (1.f / 128.f));
           }
           if (fq_x == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_abar) + ((size_t)im * 2 + wm_x) * gp->N + ncol) = mo;
@@ -1657,8 +1678,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 #pragma unroll
               for (int cc = 0; cc < 4; ++cc) {
                 float t = cs[cc];
-                t += __shfl_xor(t, 16, 64);
-                t += __shfl_xor(t, 32, 64);                                      // (p0 + p1) + (p2 + p3)
+                t = xor32_sum(xor16_sum(t));                                     // (p0 + p1) + (p2 + p3)
                 mo[cc] = (T)(t * (1.f / 128.f));
               }
               if (fq_x == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_abar) + ((size_t)im * 2 + wm_x) * gp->N + ncol) = mo;
