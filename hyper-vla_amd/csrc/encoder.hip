@@ -1479,7 +1479,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xk[mt][r]), xrs, (int)vo, (16 * mt + r) * rowb, 16);   // aux 16 = sc1
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xk[mt][r]), xrs, (int)vo, (16 * mt + r) * rowb,
+#ifdef HVLA_EXP_XSTSC1
+                                                   16);   // aux 16 = sc1
+#else
+                                                   // aux 16 = sc1 (write-through: the route through memory reads these rows), + 2 = nt at a big batch: the
+                                                   // 202 MB of x are next read a GEMM later and do not fit beside anything; streamed, they leave the
+                                                   // 101 MB of h this epilogue also writes -- the next GEMM's A operand -- in the memory-side cache
+                                                   // (same box: step 14.37 / 14.44 -> 14.23 / 14.28 ms; fc2 3.70 -> 3.62, QKV 2.50 -> 2.48)
+                                                   (NTOUT ? 18 : 16));
+#endif
       };
 #ifdef HVLA_BENCH_HOOKS
       const unsigned long long dbg_tB = __builtin_readcyclecounter();
