@@ -181,6 +181,12 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
     if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), wt_rsrc, (int)(elem_off * 4u), 0, 16);   // aux 16 = sc1
     else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + elem_off) = v;
   };
+  __amdgpu_buffer_rsrc_t nt_rsrc;
+  uint32_t nt_vo = 0;
+  if constexpr (NT && FULL && (EPI == EPI_QKV || EPI == EPI_GELU)) {
+    nt_rsrc = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, -1, 0x00020000);     // (the host asks for NT outputs below 4 GB only: 32-bit element offsets)
+    nt_vo = ((uint32_t)(g.row0 + (m_base + 4 * fq) * g.row_step) * (uint32_t)g.N + (uint32_t)n) * (uint32_t)sizeof(T);
+  }
   constexpr int RB = MT < 2 ? 1 : (EPI == EPI_RES && MT >= 4 ? 4 : 2);   // m-tiles per batch: residual loads of a batch are issued together
 #pragma unroll
   for (int mp = 0; mp < MT; mp += RB) {
@@ -253,7 +259,17 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
           // leave the GEMM's own A / W panels there.  Same box, B = 256: QKV 2.52 -> 2.40, fc1 3.80 -> 3.72, fc2 3.31 -> 3.27 ms
           // per step, the step 15.46 -> 15.25.  Small batches, whose outputs the next kernel finds in L2 / Infinity Cache, lose
           // (B = 1: 1.246 -> 1.266 ms, B = 16: +0.4 %): the host asks for it from 96 MB of output on.
+#ifdef HVLA_EXP_FLATNT
           if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]));
+#else
+          // (round 5: as a buffer store -- ONE byte offset per lane, the row as a scalar offset -- instead of a 64-bit address per
+          // row: 32 x (v_mad_u64_u32 + v_lshl_add_u64 + ...) = a hundred of an epilogue's vector instructions per wave)
+          if constexpr (NT && FULL) {
+            int rowb = g.row_step * g.N * (int)sizeof(T);
+            asm volatile("" : "+s"(rowb));                 // (opaque per site: shared, all 32 row offsets are kept in SGPRs at once)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), nt_rsrc, (int)nt_vo, ((mp + u) * 16 + r) * rowb, 2);   // aux 2 = nt
+          } else if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]));
+#endif
           else *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]) = o;
         } else if constexpr (EPI == EPI_RES) {
           f32x4 x = xin[u][r];
