@@ -126,7 +126,14 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   q = __builtin_elementwise_fma(q, a, f32x2{-0.999993085861206f, -0.999993085861206f});
   const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
   const f32x2 m = __builtin_elementwise_max(x, f32x2{0.f, 0.f});
+#ifdef HVLA_EXP_GELU_ABSX
   return __builtin_elementwise_fma(-ax, e, m);
+#else
+  // -min(|x|, 8) 2^q instead of -|x| 2^q: beyond |x| = 8 the product is below 2^-47 either way -- nothing next to x for x > 8, and zero in
+  // every 16-bit output format for x < -8 (every caller rounds to one) -- and |x| is then only an operand MODIFIER of the v_min_f32
+  // above: the packed fma cannot take one, and the v_and_b32 per element it needed was a tenth of the GELU epilogue's vector instructions.
+  return __builtin_elementwise_fma(-a, e, m);
+#endif
 }
 #endif
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
