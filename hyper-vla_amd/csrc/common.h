@@ -92,10 +92,13 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // instruction count is step time (measured: an fc1 tile is 3.4 us longer than a QKV tile of the same K).  Even form, no sign
 // transfer and no cancellation for negative x:
 //   gelu(x) = max(x, 0) - |x| Phi(-|x|),   Phi(-a) = erfc(a / sqrt 2) / 2 = exp2(q(a)),
-// q = a degree-6 minimax fit of log2 Phi(-a) on [0, 8] weighted by a Phi(-a) (tools/fit_gelu.py; |error of the product| <= 5.2e-8
-// in exact arithmetic, 8.7e-8 evaluated in f32 -- Abramowitz-Stegun 7.1.26, which this replaces, has 2.1e-7 and needs a
-// reciprocal as well: two quarter-rate transcendentals per element instead of one).  Beyond 8 the exponent is held (the
-// polynomial is not monotone out there): the product is then below 2^-50 |x|.  Six packed fmas, one v_exp_f32, min / max per element.
+// q = a minimax fit of log2 Phi(-a) on [0, 8] weighted by a Phi(-a) (tools/fit_gelu.py) -- degree 5 since round 5: |error of the product|
+// <= 4.7e-7 evaluated in f32, against an output that is rounded to 16 bits (half an ulp of a value of 0.1 is 3e-5; degree 6, rounds
+// 4-5: 8.7e-8; Abramowitz-Stegun 7.1.26, rounds 1-3: 2.1e-7 and a reciprocal as well, two transcendentals per element instead of
+// one).  One packed fma per element pair less is 0.05 ms of the step (the epilogue runs with the matrix pipe idle: every vector
+// instruction per element costs 0.07 ms); the 64-episode fixtures moved from 8.5e-4 / 7.2e-4 / 4.2e-5 to 8.0e-4 / 7.2e-4 / 4.4e-5.
+// Beyond 8 the exponent is held (the polynomial is not monotone out there): the product is then below 2^-50 |x|.  Five packed fmas +
+// one for the result, one v_exp_f32, min / max per element.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifdef HVLA_EXP_GELU_AS
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {      // round 1-3's form, kept for same-box A/B runs (tools/build_variants.sh)
@@ -118,12 +121,20 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {      // round 1-3's form, 
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   const f32x2 ax = __builtin_elementwise_abs(x);
   const f32x2 a = __builtin_elementwise_min(ax, f32x2{8.f, 8.f});
+#ifdef HVLA_EXP_GELU_DEG6
   f32x2 q = __builtin_elementwise_fma(a, f32x2{3.309331805212423e-05f, 3.309331805212423e-05f}, f32x2{-0.0007692242506891489f, -0.0007692242506891489f});
   q = __builtin_elementwise_fma(q, a, f32x2{0.008080732077360153f, 0.008080732077360153f});
   q = __builtin_elementwise_fma(q, a, f32x2{-0.05341212823987007f, -0.05341212823987007f});
   q = __builtin_elementwise_fma(q, a, f32x2{-0.4587709605693817f, -0.4587709605693817f});
   q = __builtin_elementwise_fma(q, a, f32x2{-1.1512017250061035f, -1.1512017250061035f});
   q = __builtin_elementwise_fma(q, a, f32x2{-0.999993085861206f, -0.999993085861206f});
+#else
+  f32x2 q = __builtin_elementwise_fma(a, f32x2{-0.000473309017252177f, -0.000473309017252177f}, f32x2{0.007084553595632315f, 0.007084553595632315f});
+  q = __builtin_elementwise_fma(q, a, f32x2{-0.05182736739516258f, -0.05182736739516258f});
+  q = __builtin_elementwise_fma(q, a, f32x2{-0.4599924683570862f, -0.4599924683570862f});
+  q = __builtin_elementwise_fma(q, a, f32x2{-1.150787830352783f, -1.150787830352783f});
+  q = __builtin_elementwise_fma(q, a, f32x2{-1.000037670135498f, -1.000037670135498f});
+#endif
   const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
   const f32x2 m = __builtin_elementwise_max(x, f32x2{0.f, 0.f});
 #ifdef HVLA_EXP_GELU_ABSX
