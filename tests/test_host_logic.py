@@ -219,27 +219,31 @@ def test_device_unnormalization_pairs():
 
 
 def test_gelu_polynomial_in_the_kernel_source_against_erf():
-    """csrc/common.h gelu_erf2: gelu(x) = max(x, 0) - |x| 2^q(min(|x|, 8)), q of degree 6.  The coefficients are read out of the
-    kernel source and evaluated in f32 the way the kernel does (one rounding per fma): within 2e-7 of the erf form that HF's
-    ACT2FN["gelu"] computes (transformers' Dinov2MLP), over the whole range fc1's pre-activations can reach."""
+    """csrc/common.h gelu_erf2: gelu(x) = max(x, 0) - a 2^q(a), a = min(|x|, 8), q of degree 5 (round 5; degree 6 before).  The
+    coefficients are read out of the kernel source and evaluated in f32 the way the kernel does (one rounding per fma): within 6e-7 of
+    the erf form that HF's ACT2FN["gelu"] computes (transformers' Dinov2MLP), over the whole range fc1's pre-activations can reach --
+    against an output that the epilogue rounds to 16 bits."""
     import os
     import re
     from scipy.special import erf
     src = open(os.path.join(os.path.dirname(__file__), "..", "hyper-vla_amd", "csrc", "common.h")).read()
     body = src[src.index("#else\n__device__ __forceinline__ f32x2 gelu_erf2"):]
-    body = body[:body.index("#endif")]
-    coef = [float(c) for c in re.findall(r"f32x2\{(-?[0-9.e+-]+)f,", body)]
-    assert len(coef) == 9 and coef[0] == 8.0 and coef[-1] == 0.0, coef          # clamp, c6 .. c0, the zero of max(x, 0)
-    c = np.array(coef[1:8], np.float32)                                          # highest degree first
+    clamp = [float(c) for c in re.findall(r"elementwise_min\(ax, f32x2\{(-?[0-9.e+-]+)f,", body)][0]
+    poly = body[body.index("#ifdef HVLA_EXP_GELU_DEG6"):]
+    poly = poly[poly.index("#else"):poly.index("#endif")]                         # the shipped polynomial (the #ifdef branch is the A/B variant)
+    coef = [float(c) for c in re.findall(r"f32x2\{(-?[0-9.e+-]+)f,", poly)]
+    assert clamp == 8.0 and len(coef) == 6, (clamp, coef)                       # c5 .. c0
+    assert "elementwise_fma(-a, e, m)" in body                                   # the result on the CLAMPED magnitude
+    c = np.array(coef, np.float32)                                               # highest degree first
     x = np.concatenate([np.linspace(-70, 70, 400001), np.linspace(-1, 1, 100001)]).astype(np.float32)
-    ax = np.abs(x)
-    a = np.minimum(ax, np.float32(8))
+    a = np.minimum(np.abs(x), np.float32(clamp))
     q = np.full_like(a, c[0])
     for ck in c[1:]:
         q = (q.astype(np.float64) * a + ck).astype(np.float32)
     e = np.exp2(q.astype(np.float64)).astype(np.float32)
-    got = (np.maximum(x, 0).astype(np.float64) - ax.astype(np.float64) * e).astype(np.float32)
+    got = (np.maximum(x, 0).astype(np.float64) - a.astype(np.float64) * e).astype(np.float32)
     want = 0.5 * x.astype(np.float64) * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))
     err = np.abs(got - want)
-    assert err.max() < 2e-7 + 1e-7 * 70, err.max()          # |error of the form| <= 8.7e-8; the rest is one f32 rounding of a value up to 70
-    assert np.abs(got - want)[np.abs(x) <= 8].max() < 5e-7
+    assert err.max() < 6e-7 + 1e-7 * 70, err.max()          # |error of the form| <= 4.7e-7; the rest is one f32 rounding of a value up to 70
+    assert np.abs(got - want)[np.abs(x) <= 8].max() < 1e-6
+    assert np.abs(got)[x < -8].max() < 1e-13                # beyond the clamp: zero in every 16-bit format
