@@ -77,3 +77,43 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "hvla_ref_" not in txt, f
+
+
+def test_no_kernel_of_the_library_spills_or_uses_scratch(tmp_path):
+    """Every gfx950 kernel in libhvla.so (the code objects inside its .hip_fatbin section, read with the ROCm LLVM tools): no VGPR spill,
+    no private segment.  A scratch access in one of these kernels is not only slow: behind LDS-DMA or a prefetch in flight its
+    reload waits for all of it (vmcnt retires in order) -- VERDICT r4 found two spilling instantiations in the round-4 library."""
+    import struct
+    import subprocess
+    from hypervla import _native
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    if not (os.path.exists(llvm + "llvm-objcopy") and os.path.exists(llvm + "llvm-readelf")):
+        pytest.skip("ROCm LLVM tools not installed")
+    if not os.path.exists(_native.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    fb = str(tmp_path / "fat.bin")
+    subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fb, _native.lib_path(), str(tmp_path / "x.so")], check=True)
+    data = open(fb, "rb").read()
+    magic, pos, kernels, bad = b"__CLANG_OFFLOAD_BUNDLE__", 0, 0, []
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        p = i + 32
+        for _ in range(struct.unpack_from("<Q", data, i + 24)[0]):
+            off, size, tl = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and size:
+                co = str(tmp_path / "co.elf")
+                open(co, "wb").write(data[i + off:i + off + size])
+                notes = subprocess.run([llvm + "llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+                for blk in notes.split("- .agpr_count:")[1:]:
+                    g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)
+                    kernels += 1
+                    if int(g("vgpr_spill_count")) or int(g("private_segment_fixed_size")):       # (SGPRs parked in VGPR lanes are not memory)
+                        bad.append((g("name"), g("vgpr_spill_count"), g("private_segment_fixed_size")))
+        pos = i + 24
+    assert kernels > 100, kernels
+    assert not bad, bad
