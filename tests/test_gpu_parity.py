@@ -9,6 +9,8 @@ Tolerances (floating point path; BASELINE.json north_star: actions within 1e-3 o
   end to end          README geometry: max |d action| <= 1e-3 and MAE <= 2.5e-4 over 64 episodes (three fixtures); gripper
                       compared on logits.  MID geometry (random 2-layer encoder): MAE <= 1e-3
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -369,6 +371,29 @@ def test_hf_torch_dinov2_state_dict_through_the_encoder(tmp_path):
     ref = onp.dinov2(m.params, g, dict(encoder_leaves(g)), onp.normalize_images(im[:, 0]))
     d = hid - ref
     assert hid.shape == (3, 257, 768) and np.sqrt((d * d).mean()) <= 1e-3 and np.abs(d).max() <= 1e-2, (np.sqrt((d * d).mean()), np.abs(d).max())
+
+
+def test_lane_exchange_instructions_do_what_the_kernels_assume(tmp_path):
+    """attention_kernel's column sums (a reduce-scatter over the lane bits) and the fused LayerNorm's mean rows stand on
+    v_permlane16_swap_b32 / v_permlane32_swap_b32 issued by inline asm (hipcc 7.2's builtin returns its first result twice).
+    tools/permlane_swap_probe.hip checks the hand-issued instructions' lane mapping and the reduce-scatter built on them exactly, on
+    integers; it is compiled and run here so that a toolchain or hardware that behaves otherwise is caught by name, not by a 4e-3
+    error in a second-order term that every parity test forgives."""
+    _need_gpu()
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "psp")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "permlane_swap_probe.hip")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", src, "-o", exe], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    print(out.stdout)
+    assert out.returncode == 0 and "0 of 64 lanes wrong" in out.stdout, out.stdout
+    rows = {l[:20].strip(): l[20:].split() for l in out.stdout.splitlines() if l.startswith(("builtin", "asm"))}
+    assert rows["asm, first operand"] == ["0", "15", "100", "115", "32", "47", "132", "147"]        # odd rows of a <-> even rows of b
+    assert rows["asm, second operand"] == ["16", "31", "116", "131", "48", "63", "148", "163"]
 
 
 def test_attention_with_maxima_that_grow_along_the_keys():
