@@ -396,6 +396,20 @@ def test_lane_exchange_instructions_do_what_the_kernels_assume(tmp_path):
     assert rows["asm, second operand"] == ["16", "31", "116", "131", "48", "63", "148", "163"]
 
 
+def test_attention_mean_rows_against_the_rows_the_kernel_stored():
+    """attention_kernel also writes, per (image, head), the mean of its output rows over each half of the tokens (the operand of the
+    out-projection's weight-rounding compensation).  A wrong mean row moves the actions by a second-order term that the fixtures'
+    tolerances forgive (round 5's first reduce-scatter lost a sixteenth of the rows and passed them all), so the rows are checked
+    directly: tools/attention_omean_check.py re-runs the launch on a real q / k / v (bench library, fresh process) and compares."""
+    _need_gpu()
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "attention_omean_check.py"), "8"], capture_output=True, text=True, timeout=300)
+    print(out.stdout[-600:])
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "ok", out.stdout[-600:] + out.stderr[-600:]
+
+
 def test_attention_with_maxima_that_grow_along_the_keys():
     """attention_kernel makes ONE pass over the keys: the row maximum runs along (rounded up to an integer) and O / the denominator
     are rescaled lazily, only when a key tile's maximum lies more than 8 (log2 units) above the maximum in use.  Synthetic weights
