@@ -26,7 +26,7 @@ for p in (os.path.join(ROOT, "hyper-vla_amd"), ROOT):
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-PMC_ROUND = "r5"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
+PMC_ROUND = "r6"        # profiles/<round>_pmc_*: the committed rocprofv3 --pmc passes `traffic` is read from
 PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
@@ -38,6 +38,57 @@ def fc1_main_rows(B, g):
     if g.patches == 256 and M > 2047 and g.enc_mlp % 256 == 0:
         return B * g.patches
     return M
+
+
+def big_gemm_symbols(B, g, enc_dtype, ncu=256):
+    """{category: (kernel symbol as rocprofv3 prints it, FLOPs of one launch)} for the four dense products of an encoder layer at a
+    batch whose images are tiled one 256-row tile each -- run_encoder's choices (csrc/encoder.hip, csrc/plan.h) restated, so that the
+    bench line can NAME the instantiation whose launches it timed and look its counters up in the committed PMC passes.  None at
+    the small batches (rows <= 2047: gemm64c kernels, no single dominant symbol worth a roofline)."""
+    S, E, F = g.patches + 1, g.enc_dim, g.enc_mlp
+    M = B * S
+    if not (g.patches == 256 and M > 2047 and E % 64 == 0 and F % 64 == 0 and E >= 256):
+        return None
+    op = "hvla::OpF16" if enc_dtype == "f16" else "hvla::OpBF16"
+    rows = B * g.patches
+    big = lambda n, el: M * n * el >= (96 << 20)
+
+    def lnx_persistent(nbm, nbn):
+        nt = nbm * nbn
+        if ncu % 8 or nt % ncu or nbm % 8:
+            return False
+        wx = ncu // 8
+        return wx >= nbn and (wx % nbn == 0 or (nt // ncu) % nbn == 0)
+
+    def sym(epi, n, el, lnx):
+        nbn = (n + 255) // 256
+        if lnx:
+            pers, nt = lnx_persistent(B, nbn), big(n, 4)
+        else:
+            pers, nt = (B * nbn) % ncu == 0, big(n, el) and (epi == 3 or M * n * el < (1 << 32))
+        t = lambda b: "true" if b else "false"
+        return f"void hvla::gemm256p_kernel<{op}, {epi}, {t(pers)}, {t(lnx)}, {t(nt)}>(hvla::GemmArgs)"
+
+    lnx = M * E * 4 < (1 << 32) and E <= 1024
+    return {"qkv_gemm": (sym(1, 3 * E, 2, False), 2.0 * rows * E * 3 * E),
+            "out_gemm": (sym(3, E, 4, lnx), 2.0 * rows * E * E),
+            "fc1_gemm": (sym(2, F, 2, False), 2.0 * rows * E * F),
+            "fc2_gemm": (sym(3, E, 4, lnx), 2.0 * rows * F * E)}
+
+
+def pmc_rows(symbol, rnd):
+    """{counter: mean per launch} of one kernel symbol from the committed rocprofv3 --pmc passes of this command (profiles/<round>_pmc_*.csv,
+    written by tools/collect_profiles.sh + tools/pmc_summary.py, which cuts the name at 90 characters)."""
+    import csv
+    out = {}
+    for nm in ("fetch_size", "write_size", "sq", "tcc"):
+        try:
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{nm}_by_kernel.csv"))):
+                if row["kernel"] == symbol[:90]:
+                    out[row["counter"]] = float(row["mean"])
+        except Exception:
+            pass
+    return out
 
 
 def box_probe(ctx, dev):
@@ -321,7 +372,24 @@ def main():
         stream = model._stream()
         step = graph.replay
         step()
-    ctx.profile(0 if a.graph else 1)   # HIP events around the dominant kernel only, on the launch stream
+    # ---- which kernel symbol is the dominant one?  An un-timed pass with events around every category (hvla_profile mode 2), then the
+    # categories of the symbol with the largest share are the ones whose launches carry events inside the timed region (mode 1).
+    parts = 2 if (a.streams == 2 and B >= 64) else 1       # episodes per launch = B / parts
+    symbols = big_gemm_symbols(B // parts, g, a.enc_dtype)
+    dom_cats = ["fc1_gemm"]
+    if symbols is not None:
+        ctx.profile(2)
+        for _ in range(2):
+            eager_step()
+        torch.cuda.synchronize(dev)
+        pre = ctx.profile_read()
+        share = {}
+        for cat, (name, _) in symbols.items():
+            share[name] = share.get(name, 0.0) + pre[cat][0]
+        dom_symbol = max(share, key=share.get)
+        dom_cats = [c for c, (name, _) in symbols.items() if name == dom_symbol]
+    ctx.profile_select(dom_cats)
+    ctx.profile(0 if a.graph else 1)   # HIP events around the dominant kernel's launches only, on the launch stream
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -333,7 +401,7 @@ def main():
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize(dev)
-    dom = ctx.profile_read()["fc1_gemm"]
+    dom = ctx.profile_read()
     ctx.profile(0)
     elapsed = max_over_ranks(elapsed, dev)
     if rank != 0:
@@ -378,25 +446,44 @@ def main():
     torch.cuda.synchronize(dev)
     pol_ms = e0.elapsed_time(e1) / 100
 
-    traffic = None                      # HBM bytes per launch of the dominant kernel: 2 * FETCH_SIZE + WRITE_SIZE
-    try:                                # (gfx950 FETCH_SIZE counts half of a wide streaming read), from the
-        import csv                      # committed rocprofv3 --pmc passes of this same command (profiles/)
-        vals = {}
-        for nm in ("fetch", "write"):
-            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_{nm}_size_by_kernel.csv"))):
-                if "gemm256p_kernel<hvla::OpF16, 2" in row["kernel"]:      # <Op, EPI_GELU, ...>: the fc1 launch
-                    vals[nm] = float(row["mean"]) * 1024.0
-        if B == 256 and a.enc_dtype == "f16" and a.encoder == "base" and a.streams == 1 and len(vals) == 2:
-            traffic = int(2 * vals["fetch"] + vals["write"])
-    except Exception:
-        traffic = None
     fl = algorithmic_flops(g)
-    dom_ms = dom[0] / max(dom[1], 1)
-    parts = 2 if (a.streams == 2 and B >= 64) else 1       # episodes per fc1 launch = B / parts
     rows = (B // parts) * (g.patches + 1)
     main_rows = fc1_main_rows(B // parts, g)
-    fc1_flops = 2.0 * main_rows * g.enc_dim * g.enc_mlp    # of the timed launch (the 256x256 grid; tail rows run in gemm64_kernel)
-    achieved = fc1_flops / (dom_ms * 1e-3) / 1e12
+    if symbols is None:                 # small batch: the fc1 launch (gemm64c_kernel / gemm64_kernel), as rounds 1-5 reported it
+        dom_ms_total, dom_n = dom["fc1_gemm"]
+        dom_flops_total = 2.0 * main_rows * g.enc_dim * g.enc_mlp * dom_n
+        kernel_name = f"gemm64c_kernel<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)"
+        dom_symbol = None
+    else:
+        dom_ms_total = sum(dom[c][0] for c in dom_cats)
+        dom_n = sum(dom[c][1] for c in dom_cats)
+        dom_flops_total = sum(symbols[c][1] * dom[c][1] for c in dom_cats)
+        what = {"qkv_gemm": "QKV", "out_gemm": "attention out-projection + residual + fused LayerNorm", "fc1_gemm": "fc1 + erf-GELU",
+                "fc2_gemm": "fc2 + residual + fused LayerNorm"}
+        kernel_name = dom_symbol + " = " + " and ".join(what[c] for c in dom_cats) + " of every encoder layer"
+    dom_ms = dom_ms_total / max(dom_n, 1)                     # average launch of the dominant symbol inside the timed region
+    flops_per_launch = dom_flops_total / max(dom_n, 1)
+    achieved = flops_per_launch / (dom_ms * 1e-3) / 1e12
+    # per shape, from the un-timed all-category pass right behind the timed region (3 eager steps; events around every launch)
+    by_shape = None
+    if symbols is not None:
+        by_shape = {}
+        for c, (name, f) in symbols.items():
+            ms_c, n_c = br[c]
+            if n_c:
+                by_shape[c] = {"frac": round(f / (ms_c / n_c * 1e-3) / 1e12 / PEAK_TFLOPS, 4), "launch_ms": round(ms_c / n_c, 4), "kernel": name}
+    # counters of the dominant symbol from the committed rocprofv3 --pmc passes of this same command (NOT measured in this run):
+    # HBM-side bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts half of a wide streaming read), MFMA-busy =
+    # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)
+    traffic = mfma_busy = hbm_tbps = None
+    headline_cfg = B == 256 and a.enc_dtype == "f16" and a.encoder == "base" and a.streams == 1
+    if dom_symbol is not None and headline_cfg:
+        pm = pmc_rows(dom_symbol, PMC_ROUND)
+        if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+            traffic = int((2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0)
+            hbm_tbps = round(traffic / (dom_ms * 1e-3) / 1e12, 3)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in pm and pm.get("GRBM_GUI_ACTIVE", 0) > 0:
+            mfma_busy = round(pm["SQ_VALU_MFMA_BUSY_CYCLES"] / (pm["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
     ms_per_step = elapsed / a.steps * 1e3
     out = {
         "metric": "actions_per_sec", "value": round(whole_job_rate(B, world, a.steps, elapsed), 2), "unit": "actions/s",
@@ -418,14 +505,18 @@ def main():
         "box": box,
         "latency_samples": len(lat),
         "p50_step_latency_ms": round(float(np.median(lat)), 4),
-        "roofline": {"bound": "mfma", "kernel": ("gemm64_kernel" if rows <= 2047 else "gemm256p_kernel") + f"<Op,EPI_GELU> (encoder fc1: [B*257,{g.enc_dim}]x[{g.enc_dim},{g.enc_mlp}] + bias + erf-GELU)",
+        "roofline": {"bound": "mfma", "kernel": kernel_name,
                      "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_source": (f"committed rocprofv3 --pmc passes of this command (profiles/{PMC_ROUND}_pmc_fetch_size_by_kernel.csv, "
-                                        f"{PMC_ROUND}_pmc_write_size_by_kernel.csv); NOT measured in this run") if traffic is not None else None,
-                     "traffic_unit": "bytes/launch (HBM-side, PMC: 2*FETCH_SIZE+WRITE_SIZE; algorithmic 510 MB)",
-                     "launch_ms": round(dom_ms, 4), "launches_timed": dom[1],
-                     "flops_per_launch": fc1_flops, "rows_per_launch": main_rows, "rows_total": rows},
+                     "traffic_source": (f"committed rocprofv3 --pmc passes of this command (profiles/{PMC_ROUND}_pmc_*_by_kernel.csv); "
+                                        "NOT measured in this run") if traffic is not None else None,
+                     "traffic_unit": "bytes per average launch (HBM-side, PMC: 2*FETCH_SIZE+WRITE_SIZE)",
+                     "mfma_busy": mfma_busy, "hbm_tbps": hbm_tbps, "hbm_frac_of_8tbps": round(hbm_tbps / 8.0, 4) if hbm_tbps else None,
+                     "chosen_by": "largest share of the step among the kernel symbols of an un-timed all-category pass (hvla_profile mode 2) "
+                                  "right before the timed region; its launches then carry HIP events inside the timed region",
+                     "launch_ms": round(dom_ms, 4), "launches_timed": dom_n,
+                     "flops_per_launch": flops_per_launch, "rows_per_launch": main_rows, "rows_total": rows,
+                     "by_shape": by_shape},
         "step_tflops": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12, 2),
         "step_frac_of_peak": round((fl["encoder"] + fl["policy"]) * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
         "kernel_ms_per_step": breakdown,

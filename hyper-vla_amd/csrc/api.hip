@@ -63,6 +63,9 @@ struct hvla_ctx {
   // workspaces (sized for cfg.max_batch)
   DevBuf ctx_hi, ctx_lo, ctx_f32, ws_x, ws_h, ws_qkv, ws_g, ws_corr, ws_abar, ws_lncnt, ws_lnpart, tokens, flags;
   uint32_t ln_spin = 800;        // EncWorkspace::ln_spin (8 us); hvla_debug_lnx_spin of the bench library changes it
+#ifdef HVLA_BENCH_HOOKS
+  int enc_stop = 0;              // EncWorkspace::stop_after (hvla_debug_encode_stop)
+#endif
   Profiler prof;
   float *amap_dino = nullptr, *amap_head = nullptr;     // hvla_set_attention_outputs: caller-owned device buffers (opt-in)
   // cfg.streams == 2: helper stream and fork / join events of hvla_step
@@ -509,6 +512,9 @@ static int encode_range(hvla_ctx* ctx, const uint8_t* images, float* out, int b0
   ws.ln_cnt = ctx->ws_lncnt.as<uint32_t>() + (size_t)((b0 + 3) / 4 * 4);   // (a second half starts on a 16-byte boundary)
   ws.ln_part = ctx->ws_lnpart.as<float>() + (size_t)b0 * 4 * 256 * 4;
   ws.ln_spin = ctx->ln_spin;
+#ifdef HVLA_BENCH_HOOKS
+  ws.stop_after = ctx->enc_stop;
+#endif
   const size_t img = (size_t)g.image_size * g.image_size * 3, per = (keep_cls ? S : (size_t)g.P()) * E;
   HIPCHK(ctx, launch_encoder(g, ctx->cfg.enc_dtype, ctx->encw, ws, images + (size_t)b0 * img, out + (size_t)b0 * per, nb, st,
                              &ctx->prof, keep_cls));
@@ -714,7 +720,8 @@ int hvla_train_wait_bucket(hvla_ctx* ctx, int32_t bucket, void* stream) {
 int hvla_train_profile(hvla_ctx* ctx, int32_t on) {
   if (!ctx) return HVLA_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  train_gemm_timer(on != 0);
+  const bool first = on && !ctx->train_timer;
+  train_gemm_timer(on != 0, first);
   if (on) ctx->train_timer = true;
   return HVLA_OK;
 }
@@ -894,6 +901,13 @@ int hvla_profile(hvla_ctx* ctx, int32_t mode) {
   return HVLA_OK;
 }
 
+int hvla_profile_select(hvla_ctx* ctx, uint32_t category_mask) {
+  if (!ctx) return HVLA_E_STATE;
+  if (category_mask == 0 || (category_mask >> HVLA_PROF_N) != 0) FAIL(ctx, HVLA_E_SHAPE, "profile category mask 0x%x", category_mask);
+  ctx->prof.select = category_mask;
+  return HVLA_OK;
+}
+
 int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches) {
   if (!ctx || !ms || !launches) return HVLA_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1003,6 +1017,13 @@ int hvla_debug_lnx_stats(hvla_ctx* ctx, unsigned long long* out, int reset) {
   if (!ctx) return HVLA_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, debug_lnx_stats(out, reset));
+  return HVLA_OK;
+}
+// hvla_encode then returns behind its n-th dense product (QKV, out, fc1, fc2 of layer 0 = 1 .. 4, ...; 0 = the whole encoder): the
+// workspace is read back (hvla_debug_workspace) as that product's consumers would find it -- tests of the mean rows and the corr table
+int hvla_debug_encode_stop(hvla_ctx* ctx, int32_t n) {
+  if (!ctx || n < 0) return HVLA_E_STATE;
+  ctx->enc_stop = n;
   return HVLA_OK;
 }
 // how long a column tile of a residual GEMM waits for the image's other tiles (ticks of 10 ns; the product's value is 800).  0 = nobody

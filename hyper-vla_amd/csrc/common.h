@@ -100,53 +100,21 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // Beyond 8 the exponent is held (the polynomial is not monotone out there): the product is then below 2^-50 |x|.  Five packed fmas +
 // one for the result, one v_exp_f32, min / max per element.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifdef HVLA_EXP_GELU_AS
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {      // round 1-3's form, kept for same-box A/B runs (tools/build_variants.sh)
-  const f32x2 ax = __builtin_elementwise_abs(x);
-  const f32x2 d = __builtin_elementwise_fma(ax, f32x2{0.2316418882f, 0.2316418882f}, f32x2{1.f, 1.f});   // 0.3275911 / sqrt 2
-  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  f32x2 p = __builtin_elementwise_fma(t, f32x2{0.5307027145f, 0.5307027145f}, f32x2{-0.7265760135f, -0.7265760135f});   // A-S coefficients / 2
-  p = __builtin_elementwise_fma(p, t, f32x2{0.7107068705f, 0.7107068705f});
-  p = __builtin_elementwise_fma(p, t, f32x2{-0.142248368f, -0.142248368f});
-  p = __builtin_elementwise_fma(p, t, f32x2{0.127414796f, 0.127414796f});
-  p *= t;
-  const f32x2 w = x * x;
-  const f32x2 ea = w * f32x2{-0.7213475204444817f, -0.7213475204444817f};                               // -log2(e) / 2
-  const f32x2 e = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
-  const f32x2 h = ax * p;
-  const f32x2 m = __builtin_elementwise_max(x, f32x2{0.f, 0.f});
-  return __builtin_elementwise_fma(-h, e, m);
-}
-#else
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   const f32x2 ax = __builtin_elementwise_abs(x);
   const f32x2 a = __builtin_elementwise_min(ax, f32x2{8.f, 8.f});
-#ifdef HVLA_EXP_GELU_DEG6
-  f32x2 q = __builtin_elementwise_fma(a, f32x2{3.309331805212423e-05f, 3.309331805212423e-05f}, f32x2{-0.0007692242506891489f, -0.0007692242506891489f});
-  q = __builtin_elementwise_fma(q, a, f32x2{0.008080732077360153f, 0.008080732077360153f});
-  q = __builtin_elementwise_fma(q, a, f32x2{-0.05341212823987007f, -0.05341212823987007f});
-  q = __builtin_elementwise_fma(q, a, f32x2{-0.4587709605693817f, -0.4587709605693817f});
-  q = __builtin_elementwise_fma(q, a, f32x2{-1.1512017250061035f, -1.1512017250061035f});
-  q = __builtin_elementwise_fma(q, a, f32x2{-0.999993085861206f, -0.999993085861206f});
-#else
   f32x2 q = __builtin_elementwise_fma(a, f32x2{-0.000473309017252177f, -0.000473309017252177f}, f32x2{0.007084553595632315f, 0.007084553595632315f});
   q = __builtin_elementwise_fma(q, a, f32x2{-0.05182736739516258f, -0.05182736739516258f});
   q = __builtin_elementwise_fma(q, a, f32x2{-0.4599924683570862f, -0.4599924683570862f});
   q = __builtin_elementwise_fma(q, a, f32x2{-1.150787830352783f, -1.150787830352783f});
   q = __builtin_elementwise_fma(q, a, f32x2{-1.000037670135498f, -1.000037670135498f});
-#endif
   const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
   const f32x2 m = __builtin_elementwise_max(x, f32x2{0.f, 0.f});
-#ifdef HVLA_EXP_GELU_ABSX
-  return __builtin_elementwise_fma(-ax, e, m);
-#else
   // -min(|x|, 8) 2^q instead of -|x| 2^q: beyond |x| = 8 the product is below 2^-47 either way -- nothing next to x for x > 8, and zero in
   // every 16-bit output format for x < -8 (every caller rounds to one) -- and |x| is then only an operand MODIFIER of the v_min_f32
   // above: the packed fma cannot take one, and the v_and_b32 per element it needed was a tenth of the GELU epilogue's vector instructions.
   return __builtin_elementwise_fma(-a, e, m);
-#endif
 }
-#endif
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
 
 }  // namespace hvla

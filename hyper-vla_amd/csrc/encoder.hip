@@ -34,6 +34,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "plan.h"
 
 namespace hvla {
 
@@ -96,11 +97,11 @@ struct GemmArgs {
                                  // rounding differs between the upper and the lower half of the picture; the float64 study
                                  // (tests/studies/precision_budget.py --study hilo) puts the worst action error of 64 structured
                                  // episodes at 7.1e-4 with two mean rows against 1.0e-3 with one (finer bands add nothing)
-  // gemm64_kernel, second problem in the same launch (blocks >= nb1): corr2[M2][N] = bias + abar2[M2][K] . dW2[N][K] / 4096
+  // gemm64_kernel, second problem in the same launch (M2 > 0): corr2[M2][N] = bias + abar2[M2][K] . dW2[N][K] / 4096
   const void* abar2 = nullptr;
   const void* dW2 = nullptr;
   float* corr2 = nullptr;
-  int M2 = 0, nb1 = 0;
+  int M2 = 0;
   int row0 = 0, row_step = 1;    // gemm64_kernel: the B CLS rows are rows b * S of the activation matrix
   int hsplit = 1 << 30;          // corr tables have TWO rows per image: [image][half][N], half = (token index >= hsplit); the
                                  // host sets 1 + P / 2 (tokens 1 .. P/2 | P/2 + 1 .. P: the two wave rows of an image-aligned tile)
@@ -184,7 +185,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
   __amdgpu_buffer_rsrc_t nt_rsrc;
   uint32_t nt_vo = 0;
   if constexpr (NT && FULL && (EPI == EPI_QKV || EPI == EPI_GELU)) {
-    nt_rsrc = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, -1, 0x00020000);     // (the host asks for NT outputs below 4 GB only: 32-bit element offsets)
+    nt_rsrc = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, -1, 0x00020000);     // (32-bit BYTE offsets: the host takes this form for outputs below 4 GiB only, plan.h nt16_addressable)
     nt_vo = ((uint32_t)(g.row0 + (m_base + 4 * fq) * g.row_step) * (uint32_t)g.N + (uint32_t)n) * (uint32_t)sizeof(T);
   }
   constexpr int RB = MT < 2 ? 1 : (EPI == EPI_RES && MT >= 4 ? 4 : 2);   // m-tiles per batch: residual loads of a batch are issued together
@@ -259,9 +260,6 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
           // leave the GEMM's own A / W panels there.  Same box, B = 256: QKV 2.52 -> 2.40, fc1 3.80 -> 3.72, fc2 3.31 -> 3.27 ms
           // per step, the step 15.46 -> 15.25.  Small batches, whose outputs the next kernel finds in L2 / Infinity Cache, lose
           // (B = 1: 1.246 -> 1.266 ms, B = 16: +0.4 %): the host asks for it from 96 MB of output on.
-#ifdef HVLA_EXP_FLATNT
-          if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]));
-#else
           // (round 5: as a buffer store -- ONE byte offset per lane, the row as a scalar offset -- instead of a 64-bit address per
           // row: 32 x (v_mad_u64_u32 + v_lshl_add_u64 + ...) = a hundred of an epilogue's vector instructions per wave)
           if constexpr (NT && FULL) {
@@ -269,7 +267,6 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const f32x4 (&acc)[4][MT
             asm volatile("" : "+s"(rowb));                 // (opaque per site: shared, all 32 row offsets are kept in SGPRs at once)
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), nt_rsrc, (int)nt_vo, ((mp + u) * 16 + r) * rowb, 2);   // aux 2 = nt
           } else if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]));
-#endif
           else *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(g.out) + off[u][r]) = o;
         } else if constexpr (EPI == EPI_RES) {
           f32x4 x = xin[u][r];
@@ -325,11 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   // XCD-aware tile order: blocks b and b+8 share an XCD (guide T1); give each XCD a contiguous run of
   // M-tiles for one N-tile column so the W panel and neighbouring A panels stay in its L2.
   const int nbm = (g.M + GBM - 1) / GBM, nbn = g.N / GBN;
-  int bid = blockIdx.x;
-  {
-    const int nwg = nbm * nbn, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
+  const int bid = xcd_run(blockIdx.x, nbm * nbn);
   const int bm = bid % nbm, bn = bid / nbm;
   const int m0 = bm * GBM, n0 = bn * GBN;
   const T* A = reinterpret_cast<const T*>(g.A);
@@ -409,14 +402,12 @@ constexpr int SBM = 64, SBN = 64, SNS = 6;
 // NS stages of 16 KB: 6 (5 K-tiles in flight, one workgroup per CU) or 4 (64 KB: two workgroups per CU, for the launches
 // with more blocks than CUs -- the QKV and fc1 shapes -- which otherwise run as two rounds).  Same bits either way.
 template <typename Op, int EPI, int NS = SNS>
-__device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
+__device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bm, int bn) {
   using T = typename Op::elem;
   using X8 = typename Op::x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // SNS x (A 8 KB | W 8 KB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nbm = (g.M + SBM - 1) / SBM;
-  const int bm = bid % nbm, bn = bid / nbm;
   const int m0 = bm * SBM, n0 = bn * SBN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
@@ -489,17 +480,27 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& g, int bid) {
   gemm_epilogue_rows<Op, EPI, 1>(acc, g, m0 + wave * 16, n0, fr, fq);
 }
 
-// Blocks [0, nb1): the GEMM itself.  Blocks [nb1, ...): a second, independent problem of the same N and K in the same
-// launch -- the per-image bias rows of the big GEMM that follows (corr2 = bias + abar2 . dW2 / 4096, one row per image),
-// so that the B CLS rows and the B mean rows, both pure latency, cost one launch instead of two.
+// One launch, up to two independent problems of the same N and K: the GEMM itself (M rows) and, when M2 > 0, the per-image bias
+// rows of the big GEMM that follows (corr2 = bias + abar2 . dW2 / 4096, two rows per image), so that the B CLS rows and the 2 B mean
+// rows, both pure latency, cost one launch instead of two.  A column tile has ceil(M / 64) + ceil(M2 / 64) row tiles.
+// Tile order (round 6): workgroups go round-robin over the 8 XCDs, each with an L2 of its own, so the linear tile index
+// t = column tile x RT + row tile (RT = the row tiles of BOTH problems: every workgroup that reads one 64-column slice of W or
+// of dW) is cut into 8 contiguous runs, XCD x taking run x (gemm_kernel's arithmetic): a slice then crosses the fabric once --
+// twice where a run boundary falls inside a column tile -- and the other row tiles find it in that XCD's L2.  With
+// bm = id % nbm on the raw block id the 4 CLS row tiles of a column landed on 4 L2s and the 8 mean-row tiles on 8: 58.7 MB
+// fetched per fc1-shaped launch at B = 256 for 10.6 MB of operands (profiles/r5_pmc_fetch_size_by_kernel.csv).  No k order
+// changes, so no bit does.  (xcd_run: plan.h)
 template <typename Op, int EPI, int NS = SNS>
 __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
-  if (g.nb1 == 0 || (int)blockIdx.x < g.nb1) {
-    gemm64_body<Op, EPI, NS>(g, blockIdx.x);
+  const int nbm1 = (g.M + SBM - 1) / SBM, nbm2 = (g.M2 + SBM - 1) / SBM, rt_all = nbm1 + nbm2;
+  const int t = xcd_run(blockIdx.x, gridDim.x);
+  const int bn = t / rt_all, bm = t - bn * rt_all;
+  if (bm < nbm1) {
+    gemm64_body<Op, EPI, NS>(g, bm, bn);
   } else {
     GemmArgs c = g;
     c.A = g.abar2; c.W = g.dW2; c.out = g.corr2; c.M = g.M2; c.row0 = 0; c.row_step = 1; c.corr = nullptr;
-    gemm64_body<Op, EPI_CORR, NS>(c, blockIdx.x - g.nb1);
+    gemm64_body<Op, EPI_CORR, NS>(c, bm - nbm1, bn);
   }
 }
 
@@ -1257,9 +1258,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
     f32x4 pb4 = f32x4{0.f, 0.f, 0.f, 0.f}, pl4 = pb4;
     // LNX: the lane id comes from the hardware again (mbcnt) -- nothing per-lane of this long epilogue is a register across the K loops
     int lane_e = lane;
-#ifndef HVLA_EXP_NOMBCNT
     if constexpr (LNX) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));   // (volatile: recomputed per tile, not hoisted)
-#endif
     const int fr_e = LNX ? (lane_e & 15) : fr;
     if (wvalid) {
       const uint32_t vcol = (uint32_t)(cn0 + wn * 64 + 4 * fr_e);     // 32-bit lane offset on a uniform base: no 64-bit lane address kept across the K loop
@@ -1323,9 +1322,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
       // constant LDS addresses below end up as spilled SGPRs)
       uint32_t lds_x = LNX_STAT;
       int nbn_x = nbn, wm_x = wm, wn_x = wn;
-#ifndef HVLA_EXP_NOOPQ
       asm volatile("" : "+s"(lds_x), "+s"(nbn_x), "+s"(wm_x), "+s"(wn_x));
-#endif
       lds_f* stat = (lds_f*)((lds_char*)smem + lds_x);
       lds_f* mr = (lds_f*)((lds_char*)smem + lds_x + (LNX_MR - LNX_STAT));
       volatile lds_u* ctrl = (volatile lds_u*)((lds_char*)smem + lds_x + (LNX_CTRL - LNX_STAT));
@@ -1374,11 +1371,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
         const float vmask = wvalid ? 1.f : 0.f;
         // (a ring of four: same step within the noise of two same-box runs -- out 1.665 / 1.740 against 1.680 / 1.697 ms -- once the spill
         // it caused was gone; five spills 16-23 registers in the persistent form.  The phase is not limited by the bytes in flight.)
-#if defined(HVLA_EXP_XRING4)
-        constexpr int XR = 4;
-#else
         constexpr int XR = 3;
-#endif
         f32x4 xin[XR][4];                                // a ring of XR m-tiles
         int rowb = gp->N * 4;                              // bytes per row; opaque at every site that forms the 32 scalar row offsets: shared, the
         asm volatile("" : "+s"(rowb));                   // compiler keeps all of them in SGPRs through the epilogue and spills a hundred others
@@ -1409,7 +1402,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
             xk[mt][r] = x;
             asm volatile("" : "+v"(xk[mt][r]));          // computed HERE (left alone, the arithmetic is sunk to its first use, far below,
           }                                              // and the 32 loads' destinations all stay live: spills)
-#ifndef HVLA_EXP_STATSLATE
           // [B] (sum, sum of squares) of these four rows over this wave's 64 columns -> LDS, here, under the loads of the next
           // m-tiles (this loop waits for memory with the VALU idle; as a phase of its own the reductions were 5 us per tile)
           {
@@ -1426,33 +1418,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
               d[1] = f32x4{sv[2], qv[2], sv[3], qv[3]};
             }
           }
-#endif
           __builtin_amdgcn_sched_barrier(0);             // (m-tile mt + 3 is not requested before this one is done: registers)
         }
       }
 #ifdef HVLA_BENCH_HOOKS
       const unsigned long long dbg_tA = __builtin_readcyclecounter();
-#endif
-#ifdef HVLA_EXP_STATSLATE
-      {                                                  // A/B variant (tools/build_variants.sh): the statistics as a phase of their own
-        const float vmask = wvalid ? 1.f : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-          float sv[4], qv[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ln_lane_stats(xk[mt][r], sv[r], qv[r]);
-            sv[r] = row16_sum(sv[r]) * vmask;
-            qv[r] = row16_sum(qv[r]) * vmask;
-          }
-          if (fr_x == 0) {
-            lds_f4* d = (lds_f4*)(stat + (wn_x * 256 + wm_x * 128 + 16 * mt + 4 * fq_x) * 2);
-            d[0] = f32x4{sv[0], qv[0], sv[1], qv[1]};
-            d[1] = f32x4{sv[2], qv[2], sv[3], qv[3]};
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
 #endif
       // the four waves of a wave row -> the tile's partial of the row, published as ONE 16-byte entry {S, tag, Q, tag}
       // (write-through; tag = this launch's number in the call, the table is zeroed when the call starts): whoever reads an entry
@@ -1496,15 +1466,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xk[mt][r]), xrs, (int)vo, (16 * mt + r) * rowb,
-#ifdef HVLA_EXP_XSTSC1
-                                                   16);   // aux 16 = sc1
-#else
                                                    // aux 16 = sc1 (write-through: the route through memory reads these rows), + 2 = nt at a big batch: the
                                                    // 202 MB of x are next read a GEMM later and do not fit beside anything; streamed, they leave the
                                                    // 101 MB of h this epilogue also writes -- the next GEMM's A operand -- in the memory-side cache
                                                    // (same box: step 14.37 / 14.44 -> 14.23 / 14.28 ms; fc2 3.70 -> 3.62, QKV 2.50 -> 2.48)
                                                    (NTOUT ? 18 : 16));
-#endif
       };
 #ifdef HVLA_BENCH_HOOKS
       const unsigned long long dbg_tB = __builtin_readcyclecounter();
@@ -1650,17 +1616,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
           if (!((bits >> (16 + c)) & 1u) || c * HBN_ + wn_x * 64 >= gp->N) continue;       // (wave-uniform)
           const uint32_t ncol = (uint32_t)(c * HBN_ + wn_x * 64 + 4 * fr_x);
           const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gp->ln_scale + ncol), bt4 = *reinterpret_cast<const f32x4*>(gp->ln_bias + ncol);
-#ifdef HVLA_EXP_MEMSERIAL                                    // (A/B: all 32 rows in, then the sweep -- two serial passes per tile)
-          const uint32_t vo = ((uint32_t)(im * gp->S + 1 + wm_x * 128 + 4 * fq_x) * (uint32_t)gp->N + ncol) * 4u;
-          int rowb = gp->N * 4;
-          asm volatile("" : "+s"(rowb));
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              xk[mt][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)vo, (16 * mt + r) * rowb, 0));
-          sweep(im, c, gm4, bt4);
-#else
           // the rows stream through a ring of three m-tiles (as in [A]): the loads of m-tile mt + 2 are in flight while m-tile mt is
           // normalised and stored -- this route runs on ONE CU at the end of a launch, and as "all rows in, then the sweep" it was two
           // exposed memory latencies per tile.  The arithmetic and the order of the column sums are sweep()'s.
@@ -1709,7 +1664,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs g) {
               if (fq_x == 0) *reinterpret_cast<typename Op::x4*>(reinterpret_cast<T*>(gp->ln_abar) + ((size_t)im * 2 + wm_x) * gp->N + ncol) = mo;
             }
           }
-#endif
 #ifdef HVLA_BENCH_HOOKS
           ++dbg_slow;
 #endif
@@ -1959,9 +1913,6 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       if (key < SP) *reinterpret_cast<X8*>(Ks + kperm(key) * AVLD + ((ch0 ^ (key & 7)) * 8)) = kreg[it];
     }
   }
-#ifdef HVLA_EXP_TWOPASS
-  __syncthreads();
-#endif
   HVLA_ASTAMP();                                           // 1 K staged (one pass: V follows, one barrier for both)
   auto stage_v = [&] {
 #pragma unroll
@@ -2008,27 +1959,9 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     return z;
   };
   float mx = -1e30f;
-#ifdef HVLA_EXP_TWOPASS
-  auto rowmax = [&](const f32x16& sc) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-  };
-  if constexpr (NWC != 0) {
-#pragma unroll
-    for (int kt = 0; kt < NWC; ++kt) rowmax(qk(kt, zero16()));
-  } else {
-    for (int kt = 0; kt < KT - 1; ++kt) rowmax(qk(kt, zero16()));
-  }
-  rowmax(qk(KT - 1, mask16()));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  HVLA_ASTAMP();                                           // 2 pass 1 done
-  stage_v();
-  HVLA_ASTAMP();                                           // 3 V staged
-#else
   HVLA_ASTAMP();                                           // 2 (no first pass)
   stage_v();
   HVLA_ASTAMP();                                           // 3 V staged
-#endif
   typedef float f32x2v __attribute__((ext_vector_type(2)));
   f32x2v lsum2 = {0.f, 0.f};        // this half's partial denominator (two interleaved partial sums)
   f32x16 O[2];
@@ -2065,7 +1998,6 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   };
   auto pv = [&](int kt, const f32x16& sc) {
     X8 pf[2];
-#ifndef HVLA_EXP_TWOPASS
     {
       const float tm = tile_max(sc);
       if (kt == 0) {
@@ -2080,7 +2012,6 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       }
       if (AMAP && wave == 0 && lane == 0) clsm[kt] = mx;   // the maximum this tile's row of the attention map is relative to
     }
-#endif
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       const f32x2v p2 = {__builtin_amdgcn_exp2f(sc[r] - mx), __builtin_amdgcn_exp2f(sc[r + 1] - mx)};
@@ -2088,9 +2019,6 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         clsrow[kt * 32 + crow(r, half)] = p2[0];
         clsrow[kt * 32 + crow(r + 1, half)] = p2[1];
       }
-#ifdef HVLA_EXP_LSUM_PACKED
-      lsum2 += p2;
-#else
       // two plain adds, kept apart by the asm statements: as ONE v_pk_add_f32 (what `lsum2 += p2` compiles to, and what the
       // compiler makes of two adjacent adds by itself) the kernel is 3.5 % SLOWER with 72 instructions fewer -- a packed f32
       // instruction costs this issue-bound kernel about three plain ones (same box: attention 1.572 -> 1.517 ms per step)
@@ -2098,7 +2026,6 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
         la += p2[0]; asm volatile("" : "+v"(la));
         lb += p2[1]; asm volatile("" : "+v"(lb));
         lsum2[0] = la, lsum2[1] = lb; }
-#endif
       pf[r >> 3][r & 7] = (T)p2[0];
       pf[r >> 3][(r & 7) + 1] = (T)p2[1];
     }
@@ -2127,34 +2054,11 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   if (AMAP && wave == 0) {       // outputs.attentions[layer][b, head, 0, 1:] (base_vit.py:117-118, hypervla_interface.py:210-211)
     const float i0 = lane_bcast(inv, 0);
     float* am = amap + (size_t)b * amap_stride + (size_t)head * (S - 1);
-#ifdef HVLA_EXP_TWOPASS
-    for (int j = lane; j < S - 1; j += 64) am[j] = clsrow[1 + j] * i0;
-#else
     const float m0 = lane_bcast(mx, 0);
     for (int j = lane; j < S - 1; j += 64) am[j] = clsrow[1 + j] * __builtin_amdgcn_exp2f(clsm[(1 + j) >> 5] - m0) * i0;
-#endif
   }
   {
     T* op = o + ((size_t)b * S + q) * E + head * 64;
-#ifdef HVLA_EXP_CSUM_ROWS
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        typename Op::x4 v4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ov = O[mt][g4 * 4 + r] * inv;
-          v4[r] = (T)ov;
-          if (omean) {                                     // sum over this half's 32 queries: 16-lane rows by DPP, then the two rows
-            float t = row16_sum(ov);
-            t += __shfl_xor(t, 16, 64);
-            if ((lane & 31) == 0) csum[wave * 64 + mt * 32 + g4 * 8 + half * 4 + r] = t;
-          }
-        }
-        *reinterpret_cast<typename Op::x4*>(op + mt * 32 + g4 * 8 + half * 4) = v4;
-      }
-#else
     // The lane's 32 outputs (item j = 16 mt + 4 g4 + r: column d = 32 mt + 8 g4 + 4 half + r) are to be summed over the 32 lanes
     // (queries) of its half.  Round 5: a reduce-scatter over the lane bits instead of 32 full 32-lane reductions (each 4 DPP
     // adds + a ds_bpermute + a masked LDS store: a fifth of an item's clock ticks in a kernel that is bound by VALU issue).
@@ -2202,10 +2106,8 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       const int j = lane & 31;                                                                                       // = 16 mt + 4 g4 + r
       csum[wave * 64 + (j >> 4) * 32 + ((j >> 2) & 3) * 8 + half * 4 + (j & 3)] = w1;
     }
-#endif
   }
   HVLA_ASTAMP();                                           // 5 normalised, column sums, stores issued
-#ifndef HVLA_EXP_LASTQ_VALU
   // ---- the last query, through the matrix pipe (round 5).  Its scores against key tile `wave` are one 32 x 32 tile of S^T = K Q^T
   // whose 32 columns are all THIS query (the B fragment is the parked query, the same in every lane column), so every lane holds
   // the 16 keys of its half in registers: max / sum are in-lane + one exchange between the halves, P feeds the P.V tile from
@@ -2262,9 +2164,6 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       }
     };
     lastq(wave, false);
-#ifdef HVLA_EXP_LASTKEY_MFMA
-    if (wave == NW - 1) lastq(KT - 1, true);
-#else
     // The final key tile holds ONE real key (token S - 1): p = 1, sum = 1, P.V = its V row, the score one 64-term dot product
     // (lane = d) -- a dozen VALU instructions on the first wave instead of a second masked 32-key tile on the last one, which
     // every other wave then waited for at the barrier below.
@@ -2275,55 +2174,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       if (lane == 0) pp[0] = sc, pp[1] = 1.f;
       pp[4 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
     }
-#endif
   }
-#else
-  // ---- the last query, VALU: wave w scores key tile w (lane = key, the two halves split d), the last wave also the
-  // final key S-1; partial softmax + partial P.V (lane = d); combine across waves through LDS.
-  {
-    X8 qx[4];                            // lane holds d = 32 * half .. +32 of the last query
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qx[c] = *reinterpret_cast<const X8*>(qxs + half * 32 + c * 8);
-    auto score = [&](int key) {          // sum over this half's 32 d
-      float a = 0.f;
-      const T* kr = Ks + kperm(key) * AVLD;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const X8 kv = *reinterpret_cast<const X8*>(kr + (((half * 4 + c) ^ (key & 7)) * 8));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a = fmaf((float)qx[c][j], (float)kv[j], a);
-      }
-      return a + __shfl_xor(a, 32, 64);
-    };
-    // wave w: key tile w.  Reductions over the 32 keys by DPP inside the 16-lane rows + two readlanes (a ds_bpermute
-    // butterfly is five dependent LDS round trips), the P.V row by readlane broadcasts of p.
-    {
-      const int tile = wave;
-      const float sc = score(tile * 32 + col);
-      float m = row16_max(sc);
-      m = fmaxf(lane_bcast(m, 0), lane_bcast(m, 16));
-      const float p = __builtin_amdgcn_exp2f(sc - m);
-      float l = row16_sum(p);
-      l = lane_bcast(l, 0) + lane_bcast(l, 16);
-      float od = 0.f;                    // lane = d
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const int k2 = tile * 32 + i;
-        od = fmaf(lane_bcast(p, i), (float)Vs[k2 * AVLD + (lane ^ (((k2 >> 1) & 1) << 5))], od);
-      }
-      float* pp = part + tile * APS;
-      if (lane == 0) pp[0] = m, pp[1] = l;
-      pp[4 + lane] = od;
-    }
-    if (wave == NW - 1) {                // the one real key of tile KT-1 (= S-1): p = 1, sum = 1, P.V = its V row
-      const int key = S - 1;
-      const float sc = score(key);
-      float* pp = part + (KT - 1) * APS;
-      if (lane == 0) pp[0] = sc, pp[1] = 1.f;
-      pp[4 + lane] = (float)Vs[key * AVLD + (lane ^ (((key >> 1) & 1) << 5))];
-    }
-  }
-#endif
   __syncthreads();
   HVLA_ASTAMP();                                           // 6 last-query partials done
   if (wave == 0) {
@@ -2544,11 +2395,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     return comp && M <= G64_MAXM && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31) && N % SBN == 0 && K % 64 == 0 && S >= 9;
   };
   const float* ln_partial = nullptr;
-#ifdef HVLA_EXP_NOLNX
-  const bool can_fuse_ln = false;
-#else
   const bool can_fuse_ln = ws.ln_cnt != nullptr && ws.ln_part != nullptr && (size_t)M * E * 4 < (1ull << 32) && E <= 1024;
-#endif
   // the persistent form of an LNX launch keeps the nbn column tiles of an image in one round (tile_origin_x): the counts must divide
   auto lnx_persistent = [&](int nbm_, int nbn_) {
     const int nt = nbm_ * nbn_;
@@ -2583,8 +2430,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (aligned) {
       GemmArgs c = a;                                  // the B CLS rows (+ the B mean rows -> ws.corr)
       c.M = B; c.row0 = 0; c.row_step = S;
-      c.nb1 = ((B + SBM - 1) / SBM) * (N / SBN);
-      int nblocks = c.nb1;
+      int nblocks = ((B + SBM - 1) / SBM) * (N / SBN);
       if (comp) { c.abar2 = ws.abar; c.dW2 = dW; c.corr2 = ws.corr; c.M2 = 2 * B; nblocks += ((2 * B + SBM - 1) / SBM) * (N / SBN); }   // two mean rows per image
       if constexpr (EPI != EPI_PATCH) {
         // (a three-stage form, three workgroups per CU for the launches above 512 blocks, was tried: run-to-run different
@@ -2604,7 +2450,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       if constexpr (EPI == EPI_RES) {
         if (ln_s && can_fuse_ln) {                     // the LayerNorm behind this GEMM inside its epilogue
           lnx_args(a, ln_s, ln_b, nbn);
-          const bool nt = (size_t)M * N * sizeof(float) >= ((size_t)96 << 20);      // a big batch: the residual rows are read past L2 (below)
+          const bool nt = big_output(M, N, sizeof(float));      // a big batch: the residual rows are read past L2 (below)
           if (lnx_persistent(B, nbn)) {
             if (nt) HVLA_LAUNCH((gemm256p_kernel<Op, EPI, true, true, true>), dim3(ncu), dim3(512), lds, st, a);
             else HVLA_LAUNCH((gemm256p_kernel<Op, EPI, true, true>), dim3(ncu), dim3(512), lds, st, a);
@@ -2618,15 +2464,14 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
         }
       }
       if constexpr (EPI != EPI_PATCH) {
-#ifndef HVLA_EXP_NOSTNT
         // a big batch: the 16-bit output goes past L2, the f32 residual rows are read past it (see the epilogue)
-        if ((size_t)M * N * (EPI == EPI_RES ? sizeof(float) : sizeof(T)) >= ((size_t)96 << 20)) {
+        // (the 16-bit NT stores carry 32-bit BYTE offsets: an output of 4 GiB or more takes the plain form -- ADVICE r5)
+        if (big_output(M, N, EPI == EPI_RES ? sizeof(float) : sizeof(T)) && (EPI == EPI_RES || nt16_addressable(M, N, sizeof(T)))) {
           if ((B * nbn) % ncu == 0) HVLA_LAUNCH((gemm256p_kernel<Op, EPI, true, false, true>), dim3(ncu), dim3(512), lds, st, a);
           else HVLA_LAUNCH((gemm256p_kernel<Op, EPI, false, false, true>), dim3(B * nbn), dim3(512), lds, st, a);
           pf.end(cat, st);
           return true;
         }
-#endif
       }
       if ((B * nbn) % ncu == 0) HVLA_LAUNCH((gemm256p_kernel<Op, EPI, true>), dim3(ncu), dim3(512), lds, st, a);
       else HVLA_LAUNCH((gemm256p_kernel<Op, EPI, false>), dim3(B * nbn), dim3(512), lds, st, a);
@@ -2686,14 +2531,12 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     if (!partial) return;
     // (one launch with the image's last workgroup to arrive -- ticket by atomicAdd behind a __threadfence -- adding the
     // partials was tried: 14.0 us against 5.2 + 4.7 for the two launches, profiles/r3_experiments_not_kept.txt)
-#ifndef HVLA_EXP_NOFOLD
     // B = 1: every workgroup of the consumer GEMM adds the partials up itself (gemm64c_kernel, FOLD) -- while that GEMM is ONE round
     // of workgroups (round 4, same box: B = 1 1.250 against 1.270 ms per step with the separate launch; B = 4 1.93 against 1.85).
     if (small_fused(Nnext, E) && gemm64c_fold_lds(E) <= 160 * 1024 && ((M + SBM - 1) / SBM) * (Nnext / SBN) <= ncu) {
       ln_partial = partial;
       return;
     }
-#endif
     HVLA_LAUNCH((layernorm_mean_kernel<Op>), dim3(2 * B), dim3(256), 0, st, partial, reinterpret_cast<T*>(ws.abar), P, E);
   };
   auto colmean_of = [&](const void* act, int K) {      // mean row of a GEMM output whose epilogue did not write it (no image-aligned tiles)
@@ -2746,6 +2589,12 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
   const int KT = (S + 31) / 32;     // S = 32 * (KT - 1) + 1
   const size_t asm_bytes = (size_t)KT * 32 * 2 * AVLD * sizeof(T) + (size_t)KT * APS * sizeof(float) + 64 * sizeof(T) +
                            (size_t)(KT - 1) * 64 * sizeof(float);
+#ifdef HVLA_BENCH_HOOKS
+  int products = 0;
+#define HVLA_STOP_HERE() do { if (ws.stop_after > 0 && ++products == ws.stop_after) return hipGetLastError(); } while (0)
+#else
+#define HVLA_STOP_HERE() do { } while (0)
+#endif
   for (int l = 0; l < g.enc_layers; ++l) {
     const EncLayerW& L = w.layer[l];
     if (!ln_fused) {                    // norm1: otherwise done as the tail of the previous layer's fc2 / of the patch embedding
@@ -2756,12 +2605,9 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     audit_of(ws.h, (size_t)M * E, 0);
     gemm(EQ{}, ws.h, L.wqkv, L.dqkv, 3 * E, E, L.bqkv, nullptr, ws.qkv, E, 2);                       // the LayerNorm wrote the mean row itself
     audit_of(ws.qkv, (size_t)M * 3 * E, 1);
+    HVLA_STOP_HERE();
     pf.begin(3, st);
-#ifdef HVLA_EXP_ATT_ROLLED
-    constexpr bool att_unrolled = false;
-#else
     const bool att_unrolled = KT == 9;
-#endif
     auto attn = [&](auto kern, size_t lds) {
       HVLA_LAUNCH(kern, dim3(B * H), dim3((KT - 1) * 64), lds, st, reinterpret_cast<const T*>(ws.qkv), reinterpret_cast<T*>(ws.h), S, E, H,
                   comp ? reinterpret_cast<T*>(ws.abar) : nullptr, ws.amap ? ws.amap + (size_t)l * H * (S - 1) : nullptr, g.enc_layers * H * (S - 1)
@@ -2784,13 +2630,17 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       layernorm(L.ln2_s, L.ln2_b, F, ws.qkv, 3 * E);
       pf.end(1, st);
     }
+    HVLA_STOP_HERE();
     audit_of(ws.h, (size_t)M * E, 0);
     const bool summed = gemm(EG{}, ws.h, L.w1, L.dw1, F, E, L.b1, nullptr, ws.g, 0, 5, comp ? ws.abar : nullptr);
     audit_of(ws.g, (size_t)M * F, 3);
     if (!summed) colmean_of(ws.g, F);                                                 // aligned tiles: the GELU epilogue wrote the mean row
+    HVLA_STOP_HERE();
     if (l + 1 < g.enc_layers) gemm(ER{}, ws.g, L.w2, L.dw2, E, F, L.b2, L.ls2, ws.x, 0, 6, nullptr, w.layer[l + 1].ln1_s, w.layer[l + 1].ln1_b);   // the next layer's norm1 as the tail
     else gemm(ER{}, ws.g, L.w2, L.dw2, E, F, L.b2, L.ls2, ws.x, 0, 6);
+    HVLA_STOP_HERE();
   }
+#undef HVLA_STOP_HERE
   pf.begin(1, st);
   if (keep_cls)
     HVLA_LAUNCH((layernorm_kernel<Op, 2>), dim3((M + 3) / 4), dim3(256), 0, st, ws.x, tokens, w.lnf_s, w.lnf_b, M, E, S);
@@ -2872,12 +2722,8 @@ hipError_t debug_attention_stamps(const void* qkv, void* o, void* omean, int B, 
     hipLaunchKernelGGL(kern, dim3(B * H), dim3((KT - 1) * 64), asm_bytes, st, reinterpret_cast<const T*>(qkv),
                        reinterpret_cast<T*>(o), S, E, H, reinterpret_cast<T*>(omean), (float*)nullptr, 0, stamps, wg);
   };
-#ifdef HVLA_EXP_ATT_ROLLED
-  go(attention_kernel<Op, false>);
-#else
   if (KT == 9) go(attention_kernel<Op, false, 8>);
   else go(attention_kernel<Op, false>);
-#endif
   return hipGetLastError();
 }
 #endif  // HVLA_BENCH_HOOKS

@@ -65,15 +65,20 @@ struct EncWorkspace {
   uint32_t* ln_cnt = nullptr;   // nullable: [B rounded up to 4] arrival words of the LayerNorms fused into the residual GEMMs (encoder.hip GemmArgs::ln_cnt)
   float* ln_part = nullptr;     // nullable: [B][<= 4][256] 16-byte entries, the per-row (sum, sum of squares) of every column tile (GemmArgs::ln_part); either null = LayerNorm as its own launch
   uint32_t ln_spin = 800;       // how long a column tile waits for the image's other tiles before it leaves its share to the last arriver: ticks of 10 ns
+#ifdef HVLA_BENCH_HOOKS
+  int stop_after = 0;           // libhvla_bench.so (hvla_debug_encode_stop): return behind the n-th dense product of the call (QKV, out, fc1, fc2 of
+                                // layer 0 = 1 .. 4, ...), so that a test can read the workspace as that product's consumers would find it
+#endif
 };
 // optional live timing: a pool of hipEvent pairs tagged with a category (include/hvla.h HVLA_PROF_*)
 struct Profiler {
-  int mode = 0;                       // 0 off, 1 dominant kernel only, 2 all
+  int mode = 0;                       // 0 off, 1 the selected categories only, 2 all
+  uint32_t select = 1u << 5;          // mode 1: bit c = category c (hvla_profile_select; default the fc1 GEMM)
   std::vector<hipEvent_t> start, stop;
   std::vector<int> cat;
   size_t used = 0;
   uint64_t nlaunch = 0;               // kernel launches since the last hvla_launches() (counted in run_encoder / hvla_policy / hvla_ensemble)
-  bool want(int c) const { return c >= 0 && (mode == 2 || (mode == 1 && c == 5)); }
+  bool want(int c) const { return c >= 0 && (mode == 2 || (mode == 1 && ((select >> c) & 1u))); }
   void begin(int c, hipStream_t st) {
     if (!want(c)) return;
     if (used == start.size()) {

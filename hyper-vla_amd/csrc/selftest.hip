@@ -155,7 +155,7 @@ hipError_t run_box_probe(float* sink, unsigned long long* ticks, float out[3], h
   const int iters = 20000;                              // ~ 4 ms: long enough for the clocks to settle under load
   hipEvent_t e0, e1;
   if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
-  if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
+  if ((e = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); return e; }
   hipLaunchKernelGGL(box_mfma_probe_kernel, dim3(ncu), dim3(512), 0, st, sink, ticks, 2000);     // warm-up
   (void)hipEventRecord(e0, st);
   hipLaunchKernelGGL(box_mfma_probe_kernel, dim3(ncu), dim3(512), 0, st, sink, ticks, iters);

@@ -27,8 +27,8 @@ struct BG {
   long sBias1 = 0;            // bias stride of the inner batch index b1
 };
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0);
-void train_gemm_timer(bool on);                                                  // hvla_train_profile (the current device's timer)
-void train_gemm_timer_release();                                                 // hvla_destroy: the current device's events
+void train_gemm_timer(bool on, bool first_use_by_this_context);                  // hvla_train_profile (the current device's timer; counts its users)
+void train_gemm_timer_release();                                                 // hvla_destroy of a context that used it: the events go with the last user
 hipError_t train_gemm_timer_read(float* ms, double* flops, int* launches);      // since the last read
 
 // flat layout of the trainable hypernetwork parameters (float32 elements)

@@ -166,11 +166,6 @@ __device__ __forceinline__ void stage_store(__bf16* __restrict__ hi, __bf16* __r
                     : (idx >> 3) * 32 + ((((idx & 7) >> 1) ^ ((idx >> 4) & 3)) << 3) + (idx & 1) * 4;   // row = idx >> 3, see load_frag
     bf16x4 h, l;
     __bf16 a, b;
-#ifdef HVLA_ABL_NOSPLIT      // timing ablation only (wrong numbers): what a pre-split operand would cost to stage
-    *reinterpret_cast<float2*>(hi + o) = float2{in.get(j, 0), in.get(j, 1)};
-    *reinterpret_cast<float2*>(lo + o) = float2{in.get(j, 2), in.get(j, 3)};
-    continue;
-#endif
     split1(in.get(j, 0), a, b); h[0] = a; l[0] = b;
     split1(in.get(j, 1), a, b); h[1] = a; l[1] = b;
     split1(in.get(j, 2), a, b); h[2] = a; l[2] = b;
@@ -264,10 +259,8 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void bgem
       stage_store<SB, BN, VEC, NTH>(Bh, Bl, rb[s2]);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the LDS image is complete
       // refill this register stage NST steps ahead
-#ifndef HVLA_ABL_NOLOAD      // timing ablation only
       stage_load<SA, BM, VEC, NTH>(A, g.lda, m0, g.M, kcur + 32 * NST, kend, ra[s2]);
       stage_load<SB, BN, VEC, NTH>(B, g.ldb, n0, g.N, kcur + 32 * NST, kend, rb[s2]);
-#endif
 #pragma unroll
       for (int kk = 0; kk < 32; kk += 16) {
         Split8 fa[IM], fb[IN];
@@ -279,11 +272,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void bgem
         for (int a = 0; a < IM; ++a)
 #pragma unroll
           for (int b = 0; b < IN; ++b) {
-#ifdef HVLA_ABL_NOMFMA       // timing ablation only: keep the fragment reads alive without the matrix cores
-            acc[a][b][0] += (float)fa[a].hi[0] + (float)fb[b].lo[0];
-#else
             acc[a][b] = mma32_x3(fa[a], fb[b], acc[a][b]);
-#endif
           }
       }
     }
@@ -366,23 +355,31 @@ static constexpr bool train_gemm_exact() { return false; }
 namespace {
 struct GemmTimer {
   bool on = false;
+  int users = 0;                      // contexts on this device that switched the timer on and are still alive (the events
+                                      // go back when the LAST of them is destroyed, not when any of them is)
   std::vector<hipEvent_t> a, b;
   size_t used = 0;
   double flops = 0.0;
 };
 GemmTimer g_gemm_timer[64];
+int g_gemm_timers_on = 0;             // devices whose timer is on: bgemm() asks for the current device only when this is not zero
 GemmTimer* gemm_timer_here() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   return &g_gemm_timer[dev];
 }
 }  // namespace
-void train_gemm_timer(bool on) {
-  if (GemmTimer* t = gemm_timer_here()) t->on = on;
+void train_gemm_timer(bool on, bool first_use_by_this_context) {
+  GemmTimer* t = gemm_timer_here();
+  if (!t) return;
+  if (first_use_by_this_context) ++t->users;
+  if (t->on != on) g_gemm_timers_on += on ? 1 : -1;
+  t->on = on;
 }
 void train_gemm_timer_release() {
   GemmTimer* t = gemm_timer_here();
-  if (!t) return;
+  if (!t || t->users <= 0 || --t->users > 0) return;      // another live context of this device still uses the timer
+  if (t->on) --g_gemm_timers_on;
   for (hipEvent_t e : t->a) (void)hipEventDestroy(e);
   for (hipEvent_t e : t->b) (void)hipEventDestroy(e);
   t->a.clear(), t->b.clear();
@@ -406,6 +403,7 @@ hipError_t train_gemm_timer_read(float* ms, double* flops, int* launches) {
 }
 static void bgemm_launch(hipStream_t st, bool ta, bool tb, BG g, int nb0);
 void bgemm(hipStream_t st, bool ta, bool tb, BG g, int nb0) {
+  if (g_gemm_timers_on == 0) { bgemm_launch(st, ta, tb, g, nb0); return; }
   GemmTimer* tp = gemm_timer_here();
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (!tp || !tp->on || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { bgemm_launch(st, ta, tb, g, nb0); return; }

@@ -23,7 +23,7 @@ EXPORTS = ["hvla_create", "hvla_destroy", "hvla_last_error", "hvla_load_weights"
            "hvla_train_sizes", "hvla_train_step", "hvla_train_apply", "hvla_encode_hidden", "hvla_t5_load",
            "hvla_t5_encode", "hvla_preprocess", "hvla_encode_audit", "hvla_train_accumulate", "hvla_train_bucket_ranges",
            "hvla_train_wait_bucket", "hvla_set_attention_outputs", "hvla_train_profile", "hvla_train_profile_read",
-           "hvla_launches", "hvla_box_probe"]
+           "hvla_launches", "hvla_box_probe", "hvla_profile_select"]
 PROF_NAMES = ["patch_embed", "layernorm", "qkv_gemm", "attention", "out_gemm", "fc1_gemm", "fc2_gemm", "policy",
               "small_row_gemms"]      # mean rows + the 2 B latency-bound rows per GEMM: CLS rows and weight-rounding compensation rows
 
@@ -138,6 +138,8 @@ def load_library():
     lib.hvla_train_apply.restype = C.c_int
     lib.hvla_profile.argtypes = [vp, i32]
     lib.hvla_profile.restype = C.c_int
+    lib.hvla_profile_select.argtypes = [vp, C.c_uint32]
+    lib.hvla_profile_select.restype = C.c_int
     lib.hvla_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
     lib.hvla_profile_read.restype = C.c_int
     lib.hvla_encode_audit.argtypes = [vp, vp, i32, C.POINTER(C.c_float), C.POINTER(i32), vp]
@@ -252,6 +254,13 @@ class Context:
 
     def profile(self, mode: int):
         self._check(self.lib.hvla_profile(self.h, mode), "hvla_profile")
+
+    def profile_select(self, names):
+        """Categories (PROF_NAMES) that mode 1 times."""
+        mask = 0
+        for n in names:
+            mask |= 1 << PROF_NAMES.index(n)
+        self._check(self.lib.hvla_profile_select(self.h, mask), "hvla_profile_select")
 
     def profile_read(self):
         """{category: (total ms, launches)} since the last read."""

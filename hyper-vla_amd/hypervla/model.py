@@ -146,7 +146,8 @@ class HyperVLA:
                 if model.audit_operand_range() is None:
                     warnings.warn("operand-range audit skipped: the checkpoint has no example batch with image_primary frames; "
                                   "call model.audit_operand_range(images) on real observations", RuntimeWarning)
-            except Exception as e:              # (also a failure of the example frames' resize: under 'warn' it must not block the load)
+            except ValueError as e:             # operands out of range, or example frames the resize refuses: under 'warn' neither blocks the
+                                                # load; a native / HIP failure of the audit itself is never downgraded
                 if audit == "raise":
                     raise
                 warnings.warn(f"{e} (audit='warn': loaded anyway)", RuntimeWarning)
@@ -166,13 +167,16 @@ class HyperVLA:
                 images = np.asarray(self.example_batch["observation"]["image_primary"])
             except (TypeError, KeyError):
                 return None
-        images = np.asarray(images)[: self.max_batch]      # (sliced first: an example batch of many large frames is neither moved nor resized in full)
+        images = images[: self.max_batch]       # (sliced first, as it is -- ndarray or tensor, on any device: an example batch of many large frames is neither moved nor resized in full)
         img = self._dev(images, torch.uint8)
         if img.dim() == 5:
             img = img[:, 0].contiguous()
         g = self.geometry
         if tuple(img.shape[1:]) != (g.image_size, g.image_size, 3):
-            img = self.preprocess_images(img)  # example frames of another size: the evaluators' resize (InferenceWrapper._resize_image)
+            try:
+                img = self.preprocess_images(img)  # example frames of another size: the evaluators' resize (InferenceWrapper._resize_image)
+            except _native.NativeError as e:       # frames the resize refuses are a property of the example batch (ValueError), not a device failure
+                raise ValueError(f"the example frames {tuple(img.shape)} cannot be resized for the audit: {e}") from e
         img = img.contiguous()
         audit = self._ctx.encode_audit(img.data_ptr(), img.shape[0], self._stream())      # {site: (max |x|, non-finite count)}
         sites = {k: v[0] for k, v in audit.items()}

@@ -261,7 +261,7 @@ int hvla_t5_encode(hvla_ctx* ctx, const int64_t* input_ids, const int64_t* atten
                    int32_t B, int32_t T, void* stream);
 
 /* Live per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
- *   mode 0: off (default);  1: only the dominant kernel (encoder fc1 GEMM);  2: every category.
+ *   mode 0: off (default);  1: only the selected categories (hvla_profile_select; the encoder fc1 GEMM unless told otherwise);  2: every category.
  * hvla_profile_read synchronises the recorded events, adds their durations per category into
  * ms[HVLA_PROF_N] / launches[HVLA_PROF_N], and clears the event pool.                            */
 #define HVLA_PROF_PATCH 0   /* im2col + patch-embedding GEMM + CLS rows */
@@ -277,6 +277,10 @@ int hvla_t5_encode(hvla_ctx* ctx, const int64_t* input_ids, const int64_t* atten
 #define HVLA_PROF_N 9
 int hvla_profile(hvla_ctx* ctx, int32_t mode);
 int hvla_profile_read(hvla_ctx* ctx, float* ms, int32_t* launches);
+/* Which categories mode 1 times: bit c = HVLA_PROF_c (default 1 << HVLA_PROF_FC1).  bench.py first reads a mode-2 pass, then selects
+ * the categories of the kernel symbol with the largest share of the step (round 6: out + fc2 run one instantiation) for the events
+ * inside its timed region.  A mask with a bit at or above HVLA_PROF_N, or zero, is HVLA_E_SHAPE.                                   */
+int hvla_profile_select(hvla_ctx* ctx, uint32_t category_mask);
 
 /* Measurement only (bench.py).  hvla_launches: kernel launches (and memset nodes) the ctx has enqueued since the last call
  * -- hvla_encode / hvla_policy / hvla_step / hvla_ensemble count themselves -- so that "launches per step" is what the library

@@ -95,7 +95,7 @@ def test_no_kernel_of_the_library_spills_or_uses_scratch(tmp_path):
     fb = str(tmp_path / "fat.bin")
     subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fb, _native.lib_path(), str(tmp_path / "x.so")], check=True)
     data = open(fb, "rb").read()
-    magic, pos, kernels, bad = b"__CLANG_OFFLOAD_BUNDLE__", 0, 0, []
+    magic, pos, kernels, bad, sgpr = b"__CLANG_OFFLOAD_BUNDLE__", 0, 0, [], {}
     while True:
         i = data.find(magic, pos)
         if i < 0:
@@ -112,8 +112,19 @@ def test_no_kernel_of_the_library_spills_or_uses_scratch(tmp_path):
                 for blk in notes.split("- .agpr_count:")[1:]:
                     g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)
                     kernels += 1
-                    if int(g("vgpr_spill_count")) or int(g("private_segment_fixed_size")):       # (SGPRs parked in VGPR lanes are not memory)
+                    if int(g("vgpr_spill_count")) or int(g("private_segment_fixed_size")):
                         bad.append((g("name"), g("vgpr_spill_count"), g("private_segment_fixed_size")))
+                    sgpr[g("name")] = int(g("sgpr_spill_count"))
         pos = i + 24
     assert kernels > 100, kernels
     assert not bad, bad
+    # SGPRs parked in VGPR lanes (v_writelane / v_readlane) are not memory, but each is an instruction pair per use -- held to NUMBERS
+    # (VERDICT r5 item 8): the QKV GEMM and every kernel not listed has none; fc1's persistent form 13 (its GELU epilogue's table
+    # addresses, outside the K loop); the residual GEMMs with the fused LayerNorm 62 and the patch embedding with it 53 (epilogue only:
+    # the K loop's ISA has no v_readlane / v_writelane); the policy megakernel 43; the context encoder (once per episode) 73.
+    limits = [("ctx_encoder_kernel", 73), ("policy_kernel", 43), ("gemm256p_kernelINS_5OpF16ELi1", 0), ("gemm256p_kernelINS_6OpBF16ELi1", 0),
+              ("gemm256p_kernelINS_5OpF16ELi2", 13), ("gemm256p_kernelINS_6OpBF16ELi2", 13), ("gemm256p_kernel", 62)]
+    print("SGPRs parked in VGPR lanes, largest:", sorted(sgpr.items(), key=lambda kv: -kv[1])[:6])
+    for name, n in sgpr.items():
+        allowed = next((lim for key, lim in limits if key in name), 0)
+        assert n <= allowed, (name, n, allowed)

@@ -325,8 +325,13 @@ def test_sixty_four_episodes_against_golden(case, golden_dir):
     assert max(v for v, _ in rng.values()) < 32768.0, rng             # at least a factor two below the fp16 limit
     assert np.isfinite(act).all() and np.isfinite(inter["gripper_logits"]).all()
     assert da.mean() <= tol_mae and da.max() <= tol_max, (da.mean(), da.max())
-    assert dl.max() <= 3 * tol_max, dl.max()
-    safe = np.abs(z["logits"]) > 3 * tol_max
+    # The gripper column of an action is a THRESHOLD on this logit (`logit >= 0`, action_heads.py:536): what the north star's 1e-3 on
+    # actions asks of it is the same bit wherever the logit's sign is not in doubt.  The logit itself is the head's raw linear output --
+    # not squashed by tanh x max_action like the six continuous columns, whose derivative is <= 1 -- and is held to LOGIT_TOL = 1.5e-3:
+    # the largest value measured over the three fixtures is 1.12e-3 (profiles/r5_accuracy.txt; rounds 1-5 allowed 3e-3 here).
+    LOGIT_TOL = 1.5e-3
+    assert dl.max() <= LOGIT_TOL, dl.max()
+    safe = np.abs(z["logits"]) > LOGIT_TOL
     assert (act[..., 6][safe] == z["actions"][..., 6][safe]).all()
 
 
@@ -408,6 +413,52 @@ def test_attention_mean_rows_against_the_rows_the_kernel_stored():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "attention_omean_check.py"), "8"], capture_output=True, text=True, timeout=300)
     print(out.stdout[-600:])
     assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "ok", out.stdout[-600:] + out.stderr[-600:]
+
+
+@pytest.fixture(scope="module")
+def second_order_report():
+    """tools/second_order_check.py once per module (bench library, fresh process): B = 16 at the README geometry, i.e. the big-batch
+    kernels (image-aligned tiles, the fused LayerNorm, gemm64_kernel's two problems)."""
+    _need_gpu()
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "second_order_check.py"), "16"], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-2500:])
+    assert out.stdout.strip(), out.stderr[-1500:]
+    return out.stdout.strip().splitlines()
+
+
+def _second_order_lines(report, prefix):
+    lines = [ln for ln in report if ln.startswith(prefix)]
+    assert lines, (prefix, report)
+    return lines
+
+
+def test_layernorm_mean_rows_against_the_rows_the_same_launch_stored(second_order_report):
+    """The LayerNorm fused into a residual GEMM's epilogue also writes the two mean rows per image of its output (`ln_abar`: the operand of
+    the QKV / fc1 weight-rounding compensation).  They are a second-order input -- the parity fixtures forgive a
+    mean row that is per cents wrong (What's weak 2) -- so they are checked against the column means of the `h` rows the
+    SAME launch stored, read back behind layer 1's QKV product (hvla_debug_encode_stop)."""
+    for ln in _second_order_lines(second_order_report, "ln_abar"):
+        assert ln.endswith(" ok"), ln
+
+
+def test_gelu_column_means_against_the_rows_the_same_launch_stored(second_order_report):
+    """fc1's GELU epilogue adds its ROUNDED outputs up per image half in the operand type (fc2's compensation operand): against the
+    column means of the `g` rows the launch stored."""
+    for ln in _second_order_lines(second_order_report, "GELU column means"):
+        assert ln.endswith(" ok"), ln
+
+
+def test_corr_tables_against_mean_rows_times_the_rounding_residue_in_float64(second_order_report):
+    """gemm64_kernel's second problem: corr[image][half][n] = bias[n] + (mean row . dW[n]) / 4096 -- the bias rows the big GEMMs' epilogues
+    add.  Against float64 on the mean rows read back from the device and the residue matrix dW = round16((W - round16(W)) x 4096)
+    restated from the f32 parameters (csrc/pack.h pack_matrix_t), for the QKV table of layer 1 and the fc2 table of the last layer."""
+    lines = _second_order_lines(second_order_report, "corr (")
+    assert len(lines) == 2, lines
+    for ln in lines:
+        assert ln.endswith(" ok"), ln
 
 
 def test_attention_with_maxima_that_grow_along_the_keys():
@@ -1076,3 +1127,41 @@ for nb in (8, 40, 256):
     product = _encode_in_a_fresh_process(code)
     nobody_waits = _encode_in_a_fresh_process(code, "bench")
     assert len(product.split()) == 12 and product == nobody_waits
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("geometry,enc_dtype", [("SMALL_E", "f16"), ("FULL", "bf16"), ("SMALL_E", "bf16")])
+def test_fused_layernorm_with_a_partial_column_tile_and_with_bf16_operands(geometry, enc_dtype):
+    """the LayerNorm fused into the residual GEMMs was bit-checked at E = 768 / fp16 only.  E = 384 (DINOv2-small) has
+    nbn = 2 column tiles per image and the last one is HALF wide -- the absent waves compute on the next rows' data and are zeroed
+    through `* vmask` -- and bf16 is the other operand type the library ships: every image of a batch of 8, 40 (ragged), 256
+    (persistent grid) must get the patch tokens of the same image alone (B = 1: layernorm_group_kernel), bit for bit, and with the
+    wait bound at 0 (bench library: every tile takes the route through memory) the same bytes again."""
+    _need_gpu()
+    code = f"""
+import ctypes as C, hashlib, sys, os
+sys.path.insert(0, os.path.join(os.getcwd(), "hyper-vla_amd")); sys.path.insert(0, os.getcwd())
+import torch
+from hypervla import config
+from hypervla.model import HyperVLA
+from hypervla.synthetic import synthetic_images
+g = getattr(config, "{geometry}")
+m = HyperVLA.from_synthetic(g, max_batch=256, enc_dtype="{enc_dtype}")
+if os.environ.get("HVLA_LIBRARY_FLAVOUR") == "bench":
+    m._ctx.lib.hvla_debug_lnx_spin.argtypes = [C.c_void_p, C.c_uint32]
+    assert m._ctx.lib.hvla_debug_lnx_spin(m._ctx.h, 0) == 0
+im = synthetic_images(256, g)[:, 0]
+probe = (0, 5, 7, 39, 100, 255)
+ref = {{i: m.encode_images(im[i:i + 1]).cpu()[0] for i in probe}}
+for nb in (8, 40, 256):
+    tok = m.encode_images(im[:nb]).cpu()
+    assert torch.isfinite(tok).all()
+    for i in probe:
+        if i < nb:
+            assert torch.equal(tok[i], ref[i]), (nb, i, float((tok[i] - ref[i]).abs().max()))
+    print(nb, hashlib.sha256(tok.numpy().tobytes()).hexdigest())
+"""
+    product = _encode_in_a_fresh_process(code)
+    nobody_waits = _encode_in_a_fresh_process(code, "bench")
+    assert len(product.split()) == 6 and product == nobody_waits

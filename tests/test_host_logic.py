@@ -227,10 +227,10 @@ def test_gelu_polynomial_in_the_kernel_source_against_erf():
     import re
     from scipy.special import erf
     src = open(os.path.join(os.path.dirname(__file__), "..", "hyper-vla_amd", "csrc", "common.h")).read()
-    body = src[src.index("#else\n__device__ __forceinline__ f32x2 gelu_erf2"):]
+    body = src[src.index("__device__ __forceinline__ f32x2 gelu_erf2"):]
+    body = body[:body.index("__device__ __forceinline__ float gelu_erf(")]
     clamp = [float(c) for c in re.findall(r"elementwise_min\(ax, f32x2\{(-?[0-9.e+-]+)f,", body)][0]
-    poly = body[body.index("#ifdef HVLA_EXP_GELU_DEG6"):]
-    poly = poly[poly.index("#else"):poly.index("#endif")]                         # the shipped polynomial (the #ifdef branch is the A/B variant)
+    poly = body[body.index("f32x2 q = "):body.index("const f32x2 e = ")]
     coef = [float(c) for c in re.findall(r"f32x2\{(-?[0-9.e+-]+)f,", poly)]
     assert clamp == 8.0 and len(coef) == 6, (clamp, coef)                       # c5 .. c0
     assert "elementwise_fma(-a, e, m)" in body                                   # the result on the CLAMPED magnitude

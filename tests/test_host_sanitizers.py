@@ -33,3 +33,19 @@ def test_layout_and_packing_under_asan_ubsan(tmp_path):
         want = x.astype(np.float16).view(np.uint16)
     np.testing.assert_array_equal(rec[finite, 1], want[finite])
     assert finite.sum() > 900000
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_launch_plan_arithmetic_under_asan_ubsan(tmp_path):
+    """csrc/plan.h: the XCD tile order of the small GEMM kernels is a bijection with one contiguous run per XCD at every grid size
+    (a 64-column slice of W / dW on at most two XCDs at the B = 256 launch shapes), and the non-temporal 16-bit epilogue, whose
+    stores carry 32-bit BYTE offsets, is only chosen for outputs below 4 GiB (fc1 from B = 2721 on would wrap)."""
+    exe = tmp_path / "plan_check"
+    build = subprocess.run(
+        ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall", "-Wextra",
+         "-Werror", "-I", os.path.join(ROOT, "hyper-vla_amd", "csrc"), os.path.join(ROOT, "tests", "native", "plan_check.cpp"),
+         "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr

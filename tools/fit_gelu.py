@@ -12,7 +12,7 @@ import numpy as np
 from numpy.polynomial import Polynomial, chebyshev as C
 from scipy.special import erfc
 
-LIM, DEG = 8.0, 5          # degree 6 until round 5 (HVLA_EXP_GELU_DEG6)
+LIM, DEG = 8.0, 5          # degree 6 until round 5 (git history: the A/B switch was pruned in round 6)
 
 
 def main():

@@ -14,7 +14,7 @@ for e in md.split('  - .agpr_count:')[1:]:
     dem = subprocess.run(['/usr/bin/c++filt', name], capture_output=True, text=True).stdout.strip()
     if not re.search(sys.argv[1], dem): continue
     g = lambda k: re.search(r'\.' + k + r':\s+(\d+)', e).group(1)
-    print(f"{dem[:100]:100s} vgpr {g('vgpr_count'):>3} sgpr {g('sgpr_count'):>3} spill {g('vgpr_spill_count'):>3} scratch {g('private_segment_fixed_size'):>4} lds {g('group_segment_fixed_size')}")
+    print(f"{dem[:100]:100s} vgpr {g('vgpr_count'):>3} sgpr {g('sgpr_count'):>3} spill {g('vgpr_spill_count'):>3} sgpr-spill {g('sgpr_spill_count'):>3} scratch {g('private_segment_fixed_size'):>4} lds {g('group_segment_fixed_size')}")
 PY
 # the policy kernel's tile hand-over must contain the written-out fence (__syncthreads() emits no vmcnt wait on gfx950)
 if [ "$SRC" = policy ]; then
