@@ -528,7 +528,9 @@ __global__ __launch_bounds__(256) void gemm64c_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nbm = (g.M + SBM - 1) / SBM;
-  const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
+  // (round 6) the row tiles of a column tile on ONE XCD, as in gemm64_kernel: at B = 1 the five row tiles of a 64-column slice of W
+  // and dW sat on five L2s and every slice crossed the fabric five times
+  const int tix = xcd_run(blockIdx.x, gridDim.x), bm = tix % nbm, bn = tix / nbm;
   const int m0 = bm * SBM, n0 = bn * SBN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(256) void gemm64c32_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nbm = (g.M + SBM - 1) / SBM;
-  const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
+  const int tix = xcd_run(blockIdx.x, gridDim.x), bm = tix % nbm, bn = tix / nbm;      // (see gemm64c_kernel)
   const int m0 = bm * SBM, n0 = bn * 32;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
@@ -1850,7 +1852,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   float* csum = part + KT * APS;                            // [NW][64]   per-wave column sums of the output
   float* clsm = csum + NW * 64;                            // [32]       AMAP only: the running maximum every key tile's entries of clsrow are relative to
   float* clsrow = clsm + 32;                               // [SP]       AMAP only: the CLS query's unnormalised probabilities (a region of
-                                                           // its own: `part` is written by the other waves' tails while wave 0 may still be in pass 2)
+                                                           // its own: `part` is written by the other waves' tails while wave 0 may still be in its pass over the keys)
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthr = blockDim.x;
   const size_t rowstride = (size_t)3 * E;
@@ -1859,17 +1861,89 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   const int col = lane & 31, half = lane >> 5;
   const int q = wave * 32 + col;                           // always < S - 1
   X8 qf[4];
+  constexpr bool STREAM = NWC == 8 && !AMAP;               // S = 257, 512 threads: K / V streamed in five 64-key chunks by LDS-DMA (below)
+  if constexpr (STREAM) {
+    // requested by hand: an ordinary load in flight beside the LDS-DMAs below makes the compiler wait with vmcnt(0) -- for every
+    // chunk -- before the first score MFMA (it does not count through the DMA builtins).  The registers are written by the
+    // hardware behind the compiler's back until the counted wait of the first hand-over, which is tied to them ("+v").
+    const T* qp = base + (size_t)q * rowstride + half * 8;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                 : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]) : "v"(qp) : "memory");
+  } else {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const X8*>(base + (size_t)q * rowstride + ks * 16 + half * 8);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const X8*>(base + (size_t)q * rowstride + ks * 16 + half * 8);
+  }
   // the extra query (token S-1) goes to LDS: 16 VGPRs less across the MFMA loops (the kernel runs at the 128-VGPR limit
   // of 4 waves per SIMD)
-  if (tid < 8) *reinterpret_cast<X8*>(qxs + tid * 8) = *reinterpret_cast<const X8*>(base + (size_t)(S - 1) * rowstride + tid * 8);
-  // ---- stage K and V: 16 B per thread and chunk (zero rows for the padding keys).  SP * 8 / nthr = 4 (NW + 1) / NW <= 8
+  if constexpr (!STREAM) { if (tid < 8) *reinterpret_cast<X8*>(qxs + tid * 8) = *reinterpret_cast<const X8*>(base + (size_t)(S - 1) * rowstride + tid * 8); }
+  // ---- STREAM (round 6): K and V straight into their LDS images by LDS-DMA, chunk by chunk -- K0 V0 K1 V1 ... (64 keys each: one
+  // 16-byte piece per thread and image), all requested at once; the key tiles of chunk c are worked on behind `vmcnt(pieces issued
+  // after chunk c)` + one barrier, while the later chunks are still on their way: the first score MFMA waits for 16 KB, not for
+  // 132 KB (the one-pass softmax needs nothing from later keys).  No staging registers (40 VGPRs less at the head of the kernel).
+  // The images' permutations are applied on the SOURCE side: LDS row rho of a chunk takes key kperm(rho) (K) / rho (V), its 16-byte
+  // slot gamma the source piece gamma ^ (key & 7) (K) / gamma ^ 4 on rows with bit 1 set (V).  Chunk 4 is the single key 256: its
+  // K row by lanes 0-7 of wave 0, its V row by lanes 0-7 of wave 4 (one partial-EXEC instruction each; vmcnt is counted per wave),
+  // the padding rows 257 .. 287 of both images are zeroed by ordinary stores up front.
+  X8 qlast;                                                // STREAM: the last query, wave 0's LAST request (stored behind the final hand-over)
+  auto stream_wait = [&](auto rest) {                      // rest = pieces of chunks 1-3 that may stay in flight; wave 4: + its piece of chunk 4; wave 0: + its piece and the last query; -1: nothing at all
+    constexpr int R = decltype(rest)::value;
+    if (R >= 0 && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R < 0 ? 0 : R + 2) : "memory");
+    else if (R >= 0 && wave == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R < 0 ? 0 : R + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R < 0 ? 0 : R) : "memory");
+    // the queries' registers are DEFINED here for the compiler (one statement behind all three waits: a copy it makes for this tie
+    // reads them after the data has landed; tied inside the branches, the wave-4 path got its copies IN FRONT of the wait)
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");                         // (nothing below may be placed in front of the barrier: see gemm64_body)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (STREAM) {
+    __builtin_amdgcn_sched_barrier(0);                     // the queries' loads are requested FIRST (vmcnt retires in order: their wait must not cover a chunk)
+    const int rho = tid >> 3, slot = tid & 7;              // this thread's LDS row inside a chunk (wave w: rows 8 w .. 8 w + 7) and 16-byte slot
+    const int ksrc = kperm(rho);
+    // byte offsets from `base` (uniform: an SGPR pair) of this thread's piece of chunk 0
+    const uint32_t ko = (uint32_t)(((size_t)ksrc * rowstride + E + ((slot ^ (ksrc & 7)) * 8)) * sizeof(T));
+    const uint32_t vo = (uint32_t)(((size_t)rho * rowstride + 2 * E + ((slot ^ (((rho >> 1) & 1) << 2)) * 8)) * sizeof(T));
+    const uint32_t cbytes = (uint32_t)(64 * rowstride * sizeof(T));       // between two chunks
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t kl = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024), vl = kl + (uint32_t)(SP * AVLD * sizeof(T));   // (wave-uniform: M0)
+    // issued by hand (SGPR base + 32-bit lane offset, M0 saved / written / restored inside the statement, as in gemm64c_kernel): behind
+    // the BUILTIN the compiler waits with vmcnt(0) in front of the first ds_read_b64_tr_b16 of V (it cannot tell the images apart)
+    auto dma = [&](uint32_t off, uint32_t dst) {
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");     // nt: K and V are read once per step
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dma(ko + c * cbytes, kl + c * 8192);
+      dma(vo + c * cbytes, vl + c * 8192);
+    }
+    if (wave == 0) {
+      if (lane < 8) {
+        dma(ko + 4 * cbytes, kl + 4 * 8192);
+        qlast = *reinterpret_cast<const X8*>(base + (size_t)(S - 1) * rowstride + tid * 8);
+      }
+    } else if (wave == 4) {
+      // V row 256, slots 0 .. 7 (no half swap: bit 1 of the row is clear); wave 4's own rows are 32 .. 39, so neither vo nor vl fit
+      if (lane < 8) dma((uint32_t)(((size_t)256 * rowstride + 2 * E + slot * 8) * sizeof(T)), vl - 4 * 1024 + 4 * 8192);
+    }
+    if (tid >= 8 && tid < 256) {                           // rows 257 .. 287 of both images: the padding keys
+      X8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+      *reinterpret_cast<X8*>(Ks + (256 + rho) * AVLD + slot * 8) = z;
+      *reinterpret_cast<X8*>(Vs + (256 + rho) * AVLD + slot * 8) = z;
+    }
+  }
+  // ---- (not STREAM) stage K and V: 16 B per thread and chunk (zero rows for the padding keys).  SP * 8 / nthr = 4 (NW + 1) / NW <= 8
   // chunks per thread; ALL their loads are requested before the first LDS store (a rolled loop pays one HBM round trip
   // per iteration: 5 in a row at S = 257, a third of the workgroup's life time).
-  // K first, then V: V is only needed in the second pass, so its loads stay in flight (in registers) under the first.
-  constexpr int STG = 8;
-  X8 kreg[STG], vreg[STG];
+  // K first, then V.
+  constexpr int STG = STREAM ? 0 : 8;
+  X8 kreg[STG ? STG : 1], vreg[STG ? STG : 1];
   // Round 5: the kernel is bound by instruction issue (four waves per SIMD, ~2 500 instructions per wave and item), and a fifth
   // of them were this staging: per chunk a 64-bit address, a zero fill, two compares and a branch.  Now one 32-bit offset per
   // thread into a buffer resource that ends with the image's last row: chunk `it` is 64 keys further on (a scalar offset), K
@@ -1913,7 +1987,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
       if (key < SP) *reinterpret_cast<X8*>(Ks + kperm(key) * AVLD + ((ch0 ^ (key & 7)) * 8)) = kreg[it];
     }
   }
-  HVLA_ASTAMP();                                           // 1 K staged (one pass: V follows, one barrier for both)
+  HVLA_ASTAMP();                                           // 1 K staged / STREAM: every request issued
   auto stage_v = [&] {
 #pragma unroll
     for (int it = 0; it < STG; ++it) {
@@ -1930,11 +2004,8 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   const T* vtr = Vs + ((g16 >> 1) * 4 + (i16 >> 2)) * AVLD + (g16 & 1) * 16 + (i16 & 3) * 4;
   const int kswz = col & 7;                                // K chunk swizzle of this lane's key row
   const int colp = kperm(col);                             // its row inside a 32-key tile
-  // Two passes over the resident K tiles instead of an online softmax: the matrix pipe is idle most of the
-  // time here (head_dim 64: 8 MFMAs per 1024 scores), so recomputing K.Q^T (4 MFMAs) is cheaper than the
-  // per-tile rescale of O and the running-max bookkeeping.
-  //   pass 1: row max (scores are in the log2 domain: q carries 1/sqrt(64) * log2 e from the QKV epilogue)
-  //   pass 2: accumulator initialised to -max, so p = exp2(acc) with no subtract; invalid keys get -1e30
+  // One pass over the key tiles (round 5; the pass is described at pv() below): scores are in the log2 domain (q carries
+  // 1/sqrt(64) * log2 e from the QKV epilogue), the padding keys of the last tile get -1e30 through the accumulator input.
   auto kfrag = [&](int kt, int ks) {
     return *reinterpret_cast<const X8*>(Ks + (kt * 32 + colp) * AVLD + (((2 * ks + half) ^ kswz) * 8));
   };
@@ -1959,9 +2030,11 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
     return z;
   };
   float mx = -1e30f;
-  HVLA_ASTAMP();                                           // 2 (no first pass)
-  stage_v();
-  HVLA_ASTAMP();                                           // 3 V staged
+  HVLA_ASTAMP();                                           // 2 (rounds 1-4: the first pass over the keys)
+  if constexpr (!STREAM) {
+    stage_v();
+    HVLA_ASTAMP();                                         // 3 V staged
+  }
   typedef float f32x2v __attribute__((ext_vector_type(2)));
   f32x2v lsum2 = {0.f, 0.f};        // this half's partial denominator (two interleaved partial sums)
   f32x16 O[2];
@@ -2042,7 +2115,24 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   // (The scores relative to the maximum in use -- -max as the accumulator input of a tile's first MFMA, one tuple of 16 registers
   // rewritten only when the maximum moves, p = exp2(score) with no subtraction: 16 instructions less per key tile -- was built: 1 %.
   // After the one-pass form this kernel is no longer bound by its VALU instruction count.)
-  if constexpr (NWC != 0) {
+  if constexpr (STREAM) {
+    using std::integral_constant;
+    stream_wait(integral_constant<int, 6>{});              // chunk 0 (keys 0 .. 63) is in LDS for every wave
+    HVLA_ASTAMP();                                         // 3 (STREAM) the first hand-over: what the head of the workgroup waits for
+    pv(0, qk(0, zero16()));
+    pv(1, qk(1, zero16()));
+    stream_wait(integral_constant<int, 4>{});
+    pv(2, qk(2, zero16()));
+    pv(3, qk(3, zero16()));
+    stream_wait(integral_constant<int, 2>{});
+    pv(4, qk(4, zero16()));
+    pv(5, qk(5, zero16()));
+    stream_wait(integral_constant<int, 0>{});
+    pv(6, qk(6, zero16()));
+    pv(7, qk(7, zero16()));
+    if (tid < 8) *reinterpret_cast<X8*>(qxs + tid * 8) = qlast;      // (the compiler waits for it with vmcnt(0): everything has landed)
+    stream_wait(integral_constant<int, -1>{});             // key 256, the zero rows, the last query
+  } else if constexpr (NWC != 0) {
 #pragma unroll
     for (int kt = 0; kt < NWC; ++kt) pv(kt, qk(kt, zero16()));
   } else {
@@ -2050,7 +2140,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   }
   pv(KT - 1, qk(KT - 1, mask16()));
   const float inv = 1.f / half_exchange_sum(lsum2[0] + lsum2[1]);
-  HVLA_ASTAMP();                                           // 4 pass 2 done
+  HVLA_ASTAMP();                                           // 4 the pass over the keys done
   if (AMAP && wave == 0) {       // outputs.attentions[layer][b, head, 0, 1:] (base_vit.py:117-118, hypervla_interface.py:210-211)
     const float i0 = lane_bcast(inv, 0);
     float* am = amap + (size_t)b * amap_stride + (size_t)head * (S - 1);
@@ -2111,7 +2201,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
   // ---- the last query, through the matrix pipe (round 5).  Its scores against key tile `wave` are one 32 x 32 tile of S^T = K Q^T
   // whose 32 columns are all THIS query (the B fragment is the parked query, the same in every lane column), so every lane holds
   // the 16 keys of its half in registers: max / sum are in-lane + one exchange between the halves, P feeds the P.V tile from
-  // registers exactly as in pass 2, and the partial (max, sum, O[64]) goes to LDS from one lane column.  On the VALU (rounds 1-4:
+  // registers exactly as in the pass over the keys, and the partial (max, sum, O[64]) goes to LDS from one lane column.  On the VALU (rounds 1-4:
   // 32 fma per key with converts, a 32-step readlane loop for P.V) this was 9 400 of an item's 34 000 clock ticks in a kernel whose
   // two workgroups per CU contend for VALU issue (profiles/r5_experiments_not_kept.txt 5).  The last wave also takes the final key
   // tile (one real key, the rest masked).
@@ -2136,7 +2226,7 @@ __global__ void attention_kernel(const typename Op::elem* __restrict__ qkv, type
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const float p0 = __builtin_amdgcn_exp2f(c[r] - m), p1 = __builtin_amdgcn_exp2f(c[r + 1] - m);
-        la += p0; asm volatile("" : "+v"(la));       // (plain adds: see pass 2)
+        la += p0; asm volatile("" : "+v"(la));       // (plain adds: see pv())
         lb += p1; asm volatile("" : "+v"(lb));
         pf[r >> 3][r & 7] = (T)p0;
         pf[r >> 3][(r & 7) + 1] = (T)p1;

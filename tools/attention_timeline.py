@@ -26,7 +26,7 @@ lib.hvla_debug_attention_stamps.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c
 rc = lib.hvla_debug_attention_stamps(m._ctx.h, B, arr, len(wgs), out)
 assert rc == 0, rc
 t = np.array(list(out), dtype=np.float64).reshape(len(wgs), 8)
-names = ["K loaded + staged", "pass 1 (row max)", "V staged", "pass 2 (exp2, P.V)", "normalise + column sums + stores", "last query partials", "combine + end"]
+names = ["requests issued (LDS-DMA, q)", "address set-up", "wait for chunk 0", "pass over the keys (+ 4 hand-overs)", "normalise + column sums + stores", "last query partials", "combine + end"]
 print(f"B = {B}: {n_wg} workgroups; clock ticks per phase (wave 0)")
 print("workgroup".ljust(10) + "".join(n[:22].rjust(24) for n in names) + "total".rjust(10))
 for i, w in enumerate(wgs):

@@ -81,8 +81,9 @@ def residue(kernels):
     return round16((w - round16(w)) * np.float32(4096.0)).astype(np.float64).T
 
 
-def leaf(layer, *path):
-    return np.asarray(m.params[shared_name(("encoder", "layer", str(layer)) + path)])
+def leaf(layer, *path, shape=None):
+    a = np.asarray(m.params[shared_name(("encoder", "layer", str(layer)) + path)])      # (synthetic parameters are stored flat)
+    return a.reshape(shape) if shape is not None else a
 
 
 def half_means(rows):
@@ -114,9 +115,9 @@ eps16 = 2.0 ** -11 if dt == "f16" else 2.0 ** -8
 # the kernel adds the f32 values up and rounds the mean once; the rows it stored are rounded one by one: the two differ by the mean of
 # P/2 independent roundings of values of the rows' size plus one rounding of the mean
 report("ln_abar vs the column means of the h rows the same launch stored", abar, half_means(h), 2.0 * eps16)
-dqkv = residue([leaf(1, "attention", "attention", nm, "kernel") for nm in ("query", "key", "value")])
+dqkv = residue([leaf(1, "attention", "attention", nm, "kernel", shape=(E, E)) for nm in ("query", "key", "value")])
 bqkv = np.concatenate([leaf(1, "attention", "attention", nm, "bias") for nm in ("query", "key", "value")]).astype(np.float64)
-report("corr (QKV) vs bias + abar . dW / 4096 in float64", corr, bqkv + abar @ dqkv.T / 4096.0, 2e-6)
+report("corr (QKV) vs bias + abar . dW / 4096 in float64", corr, bqkv + abar @ dqkv.T / 4096.0, 5e-8)
 # the size of what the table corrects, for scale: how far it is from the plain bias
 print(f"   (the table moves the bias by up to {np.abs(corr - bqkv).max():.2e}; a table that ignored the mean rows would be off by that)")
 
@@ -129,9 +130,9 @@ corr2 = grab(4, B * 2 * E * 4).view(np.float32).astype(np.float64).reshape(B, 2,
 # the epilogue adds the ROUNDED outputs up in the operand type itself (two v_pk_add_f16 per row; colmean_kernel restates it): the
 # sum of 32 values per lane carries the operand type's rounding at every step, then f32 over the lanes / waves
 report("GELU column means vs the column means of the g rows the same launch stored", cm, half_means(gl), 16.0 * eps16)
-dw2 = residue([leaf(L, "mlp", "fc2", "kernel")])
+dw2 = residue([leaf(L, "mlp", "fc2", "kernel", shape=(F, E))])
 b2 = leaf(L, "mlp", "fc2", "bias").astype(np.float64)
-report("corr (fc2) vs bias + colmean . dW2 / 4096 in float64", corr2, b2 + cm @ dw2.T / 4096.0, 2e-6)
+report("corr (fc2) vs bias + colmean . dW2 / 4096 in float64", corr2, b2 + cm @ dw2.T / 4096.0, 5e-8)
 print(f"   (the table moves the bias by up to {np.abs(corr2 - b2).max():.2e})")
 print("ok" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
