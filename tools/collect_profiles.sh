@@ -3,7 +3,7 @@
 # gpurun_out/p that profiles/ keeps for this round.  rocprofv3 gets the program itself after `--` (python3 ...); counter
 # passes (--pmc) are separate runs with --kernel-trace only.
 set -u
-RND=${1:-r2}
+RND=${1:-r6}
 R=$(pwd); P=$R/gpurun_out/p; mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/prof_b256 -- python3 $R/bench.py --steps 10 --warmup 2 --latency-samples 10 --no-cpu-baseline > $P/${RND}_bench_b256_under_rocprof.json 2>/dev/null
@@ -20,8 +20,8 @@ cp $P/prof_b1/*/*_kernel_stats.csv $P/${RND}_bench_b1_kernel_stats.csv
 rm -rf $P/prof_b256 $P/prof_ft $P/prof_b1
 mv $P/summary_FETCH_SIZE.csv $P/${RND}_pmc_fetch_size_by_kernel.csv; mv $P/summary_WRITE_SIZE.csv $P/${RND}_pmc_write_size_by_kernel.csv
 mv $P/summary_sq.csv $P/${RND}_pmc_sq_by_kernel.csv; mv $P/summary_tcc.csv $P/${RND}_pmc_tcc_by_kernel.csv
-# the bench line reads its `roofline.traffic` from profiles/<round>_pmc_{fetch,write}_size_by_kernel.csv: refresh them first
-cp $P/${RND}_pmc_fetch_size_by_kernel.csv $P/${RND}_pmc_write_size_by_kernel.csv $R/profiles/
+# the bench line reads `roofline.traffic` / `mfma_busy` / `hbm_tbps` of its dominant kernel from profiles/<round>_pmc_*_by_kernel.csv: refresh them first
+cp $P/${RND}_pmc_fetch_size_by_kernel.csv $P/${RND}_pmc_write_size_by_kernel.csv $P/${RND}_pmc_sq_by_kernel.csv $P/${RND}_pmc_tcc_by_kernel.csv $R/profiles/
 timeout 600 python bench.py > $P/${RND}_bench_b256.json 2>$P/err1.log
 timeout 600 python bench.py --graph --batch 2048 --steps 20 --warmup 20 --no-cpu-baseline > $P/${RND}_bench_b2048_graph.json 2>/dev/null
 timeout 600 python bench.py --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline > $P/${RND}_bench_b1024.json 2>/dev/null
@@ -43,6 +43,8 @@ timeout 300 python tools/lnx_stats.py 256 > $P/${RND}_lnx_stats.txt 2>/dev/null
 timeout 300 python tools/lnx_check.py 800 8 9 40 64 85 86 255 256 512 > $P/${RND}_lnx_same_bytes.txt 2>/dev/null
 timeout 300 python tools/lnx_check.py 0 8 64 256 512 >> $P/${RND}_lnx_same_bytes.txt 2>/dev/null
 timeout 300 python tools/attention_timeline.py 256 > $P/${RND}_attention_timeline.txt 2>/dev/null
+timeout 300 python tools/second_order_check.py 16 > $P/${RND}_second_order_inputs.txt 2>/dev/null
+timeout 300 python tools/second_order_check.py 16 bf16 >> $P/${RND}_second_order_inputs.txt 2>/dev/null
 { timeout 300 python tools/attention_omean_check.py 16 2>/dev/null | tail -5
   hipcc --offload-arch=gfx950 -O3 tools/permlane_swap_probe.hip -o /tmp/psp 2>/dev/null && timeout 60 /tmp/psp; } > $P/${RND}_attention_mean_rows_and_swap_probe.txt 2>&1
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -s -m gpu -k "sixty_four or full_geometry_against_golden" 2>/dev/null | grep -E "npz|passed|failed" > $P/${RND}_accuracy.txt
