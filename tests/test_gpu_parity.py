@@ -222,6 +222,34 @@ def test_error_behaviour(mid):
         m.create_tasks(instruction_dict=big, initial_state={"patch_embeddings": np.repeat(mid["st"]["patch_embeddings"], 4, 0)})
 
 
+def test_profile_select_times_the_selected_categories_only(mid):
+    """include/hvla.h hvla_profile_select (round 6): mode 1 records HIP events around the launches of the selected categories only -- what
+    bench.py uses to time the dominant kernel symbol inside its timed region -- mode 2 around all; a zero mask or a bit at or above
+    HVLA_PROF_N is refused."""
+    from hypervla import _native
+    from hypervla.config import MID
+    m = mid["model"]
+    ctx = m._ctx
+    w, tasks, _ = m.create_tasks(instruction_dict=mid["ins"], initial_state=mid["st"])
+    step = lambda: m.sample_actions(mid["im"], mid["ins"], tasks, None, w)
+    ctx.profile(2)
+    step()
+    every = ctx.profile_read()
+    assert every["qkv_gemm"][1] == MID.enc_layers and every["fc2_gemm"][1] == MID.enc_layers and every["policy"][1] == 1
+    ctx.profile_select(["out_gemm", "fc2_gemm"])
+    ctx.profile(1)
+    step()
+    some = ctx.profile_read()
+    assert {k for k, v in some.items() if v[1]} == {"out_gemm", "fc2_gemm"}
+    assert some["out_gemm"][1] == MID.enc_layers and some["out_gemm"][0] > 0.0
+    ctx.profile(0)
+    step()
+    assert all(v[1] == 0 for v in ctx.profile_read().values())
+    for bad in (0, 1 << len(_native.PROF_NAMES)):
+        assert ctx.lib.hvla_profile_select(ctx.h, bad) == -1          # HVLA_E_SHAPE
+    ctx.profile_select(["fc1_gemm"])                                    # the default again
+
+
 def test_generate_reuses_the_arena_of_the_previous_episode_batch(mid):
     """include/hvla.h: hvla_generate allocates only when the ctx holds no arena of that batch size; an arena handed back by
     hvla_weights_free (episode reset) is reused, with the same generated parameters and no growth of device memory."""
