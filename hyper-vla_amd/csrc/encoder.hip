@@ -2516,8 +2516,8 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
     // N % 256 != 0 (DINOv2-small: 384, 1152): the last tile column is 64, 128 or 192 wide, the rest of its MFMAs wasted (33 % at
     // N = 384) -- still twice as fast as the 128 x 128 register-staged kernel
     const bool aligned = P == HBM_ && N % SBN == 0 && N >= HBN_ && M > G64_MAXM && K >= 128 && K % 64 == 0 && fits32;
-    pf.begin(CAT_COMP, st);
     if (aligned) {
+      pf.begin(CAT_COMP, st);
       GemmArgs c = a;                                  // the B CLS rows (+ the B mean rows -> ws.corr)
       c.M = B; c.row0 = 0; c.row_step = S;
       int nblocks = ((B + SBM - 1) / SBM) * (N / SBN);
@@ -2572,8 +2572,7 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       // (S >= 9: a block's 64 rows then belong to at most 8 images = the 16 rows of the kernels' bias-row tile)
       if (small_fused(N, K)) {                           // small batch: the bias rows are computed inside the GEMM
         a.abar2 = ws.abar; a.dW2 = dW; a.M2 = 2 * B;
-        pf.end(CAT_COMP, st);
-        pf.begin(cat, st);
+        pf.begin(cat, st);                               // (no launch of its own for the bias rows: nothing is timed as HVLA_PROF_COMP)
         const int nb64 = ((M + SBM - 1) / SBM) * (N / SBN);
         if constexpr (EPI != EPI_RES) {
           if (ln_partial) {                              // the LayerNorm in front left the mean rows to this launch
@@ -2597,11 +2596,12 @@ static hipError_t run_encoder(const Geom& g, const EncWeights& w, const EncWorks
       }
     }
     if (comp) {                                        // the same gemm64_body<EPI_CORR> arithmetic as the fused launch above
+      pf.begin(CAT_COMP, st);
       GemmArgs c{ws.abar, dW, 2 * B, N, K, bias, nullptr, ws.corr, P, S, 0, 1.f};
       HVLA_LAUNCH((gemm64_kernel<Op, EPI_CORR>), dim3(((2 * B + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, c);
       a.corr = ws.corr;
+      pf.end(CAT_COMP, st);
     }
-    pf.end(CAT_COMP, st);
     pf.begin(cat, st);
     if (M <= G64_MAXM && fits32 && N % SBN == 0 && K % 64 == 0)
       HVLA_LAUNCH((gemm64_kernel<Op, EPI>), dim3(((M + SBM - 1) / SBM) * (N / SBN)), dim3(256), SNS * 16384, st, a);
