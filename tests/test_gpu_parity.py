@@ -939,14 +939,17 @@ def test_config3_size_graph_replay_and_invariance():
         np.testing.assert_array_equal(np.asarray(a), full_a[lo:lo + 64])
 
 
-def test_two_stream_step_gives_the_same_bytes():
+@pytest.mark.parametrize("B", [96, 256, 37])
+def test_two_stream_step_gives_the_same_bytes(B):
     """hvla_config.streams = 2: the two halves of the batch on two streams (also under hipGraph capture) return exactly the
-    single-stream actions."""
+    single-stream actions -- at 96 episodes (two halves of one round of tiles each), at the headline batch (two halves of 128: the
+    fused LayerNorm's one-workgroup-per-tile form beside the other half's persistent launches of other shapes) and at a
+    ragged one (19 + 18)."""
     _need_gpu()
     from hypervla import synthetic as syn
     from hypervla.config import FULL
     from hypervla.model import HyperVLA
-    g, B = FULL, 96
+    g = FULL
     ins, st, im = syn.synthetic_instructions(B, g), syn.synthetic_initial_state(B, g), syn.synthetic_images(B, g)
     outs = []
     for streams in (1, 2):
