@@ -247,3 +247,34 @@ def test_gelu_polynomial_in_the_kernel_source_against_erf():
     assert err.max() < 6e-7 + 1e-7 * 70, err.max()          # |error of the form| <= 4.7e-7; the rest is one f32 rounding of a value up to 70
     assert np.abs(got - want)[np.abs(x) <= 8].max() < 1e-6
     assert np.abs(got)[x < -8].max() < 1e-13                # beyond the clamp: zero in every 16-bit format
+
+
+def test_bench_names_the_kernel_symbols_the_committed_profile_lists():
+    """bench.py::big_gemm_symbols restates run_encoder's launch choices so that the bench line can NAME the instantiation it timed and look
+    its counters up in the committed PMC passes.  The names it produces for the headline configuration must be symbols
+    of the committed rocprofv3 statistics of that very command -- and the one with the largest share must be their top row."""
+    import csv
+    import importlib.util
+    import os
+    root = os.path.join(os.path.dirname(__file__), "..")
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from hypervla.config import FULL, SMALL_E
+    rows = list(csv.DictReader(open(os.path.join(root, "profiles", f"{bench.PMC_ROUND}_bench_b256_kernel_stats.csv"))))
+    share = {r["Name"]: float(r["Percentage"]) for r in rows}
+    sym = bench.big_gemm_symbols(256, FULL, "f16")
+    assert set(sym) == {"qkv_gemm", "out_gemm", "fc1_gemm", "fc2_gemm"}
+    for cat, (name, flops) in sym.items():
+        assert name in share, (cat, name)
+        assert flops > 0
+    assert sym["out_gemm"][0] == sym["fc2_gemm"][0] == rows[0]["Name"]            # one instantiation, the profile's top row
+    assert sym["fc1_gemm"][1] == 2.0 * 256 * 256 * 768 * 3072
+    # the PMC lookup of that symbol finds all four counters' files
+    pm = bench.pmc_rows(rows[0]["Name"], bench.PMC_ROUND)
+    assert {"FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"} <= set(pm)
+    # small batches have no dominant 256 x 256 symbol; DINOv2-small and two half-batches name other instantiations
+    assert bench.big_gemm_symbols(4, FULL, "f16") is None
+    assert "OpBF16" in bench.big_gemm_symbols(256, FULL, "bf16")["qkv_gemm"][0]
+    assert bench.big_gemm_symbols(128, FULL, "f16")["out_gemm"][0].endswith("3, false, true, true>(hvla::GemmArgs)")
+    assert bench.big_gemm_symbols(256, SMALL_E, "f16") is not None
